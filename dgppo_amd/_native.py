@@ -1,0 +1,155 @@
+"""ctypes binding of libdgppo_hip.so (C ABI: include/dgppo_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module raises at import
+of the first symbol, and every wrapper refuses non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdgppo_hip.so")
+
+ABI_VERSION = 1
+
+ENV_KINDS = {"LidarSpread": 0, "LidarTarget": 1, "LidarBicycleTarget": 2, "MPESpread": 3, "MPETarget": 4}
+RECT_STRIDE = 16
+
+
+class EnvCfg(C.Structure):
+    """struct dgppo_env_cfg"""
+    _fields_ = [
+        ("kind", C.c_int32), ("n_agents", C.c_int32), ("n_goals", C.c_int32), ("n_obs", C.c_int32),
+        ("n_rays", C.c_int32), ("top_k", C.c_int32), ("state_dim", C.c_int32), ("node_dim", C.c_int32),
+        ("area_size", C.c_float), ("dt", C.c_float), ("car_radius", C.c_float), ("comm_radius", C.c_float),
+        ("obs_radius", C.c_float), ("dist2goal", C.c_float), ("two_car_radius", C.c_float),
+        ("lidar_mask_radius", C.c_float), ("eye_offset", C.c_float), ("car_plus_obs", C.c_float),
+        ("vel_limit", C.c_float), ("reset_min_dist", C.c_float),
+    ]
+
+    # ---- derived sizes (mirror csrc/common.h) ----
+    @property
+    def is_lidar(self):
+        return self.kind <= 2
+
+    @property
+    def is_spread(self):
+        return self.kind in (0, 3)
+
+    @property
+    def obs_nodes(self):
+        if self.is_lidar:
+            return self.n_agents * self.top_k if self.n_obs > 0 else 0
+        return self.n_obs
+
+    @property
+    def obs_slots(self):
+        if self.is_lidar:
+            return self.top_k if self.n_obs > 0 else 0
+        return self.n_obs
+
+    @property
+    def goal_slots(self):
+        return self.n_goals if self.is_spread else 1
+
+    @property
+    def num_nodes(self):
+        return self.n_agents + self.n_goals + self.obs_nodes + 1
+
+    @property
+    def num_edges(self):
+        return self.n_agents * (self.n_agents + self.goal_slots + self.obs_slots)
+
+    @property
+    def fan_in(self):
+        return self.n_agents + self.goal_slots + self.obs_slots
+
+    @property
+    def obst_stride(self):
+        return RECT_STRIDE if self.is_lidar else self.state_dim
+
+
+def make_env_cfg(kind: int, n_agents: int, n_obs: int, n_rays: int = 32, top_k: int = 8, area_size: float = 1.5,
+                 dt: float = 0.03, car_radius: float = 0.05, comm_radius: float = 0.5, obs_radius: float = 0.05,
+                 dist2goal: float = 0.01) -> EnvCfg:
+    """Thresholds are formed in Python doubles then rounded to fp32, exactly as the reference's weakly-typed
+    Python floats are (e.g. `comm_radius - 1e-1`, dgppo/env/lidar_env/lidar_spread.py:88)."""
+    is_lidar = kind <= 2
+    sd = 5 if kind == 2 else 4
+    c = EnvCfg()
+    c.kind, c.n_agents, c.n_goals, c.n_obs = kind, n_agents, n_agents, n_obs
+    c.n_rays, c.top_k = (n_rays, top_k) if is_lidar else (0, 0)
+    c.state_dim, c.node_dim = sd, sd + 3
+    c.area_size, c.dt, c.car_radius, c.comm_radius = area_size, dt, car_radius, comm_radius
+    c.obs_radius, c.dist2goal = obs_radius, dist2goal
+    c.two_car_radius = car_radius * 2
+    c.lidar_mask_radius = comm_radius - 1e-1
+    c.eye_offset = comm_radius + 1
+    c.car_plus_obs = car_radius + obs_radius
+    c.vel_limit = 0.5 if is_lidar else 1.0
+    c.reset_min_dist = (2.2 * car_radius) if is_lidar else (2 * car_radius)
+    return c
+
+
+class GraphOut(C.Structure):
+    """struct dgppo_graph_out"""
+    _fields_ = [(k, C.c_void_p) for k in
+                ("nodes", "edges", "states", "receivers", "senders", "node_type", "n_node", "n_edge")]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library or fail loudly (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"dgppo_amd: HIP library not built: {LIB_PATH} is missing. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dgppo_amd/csrc`). "
+            "There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    l.dgppo_abi_version.restype = C.c_int32
+    l.dgppo_last_error.restype = C.c_char_p
+    v = l.dgppo_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"dgppo_amd: ABI mismatch: library {v}, python {ABI_VERSION}")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().dgppo_last_error().decode("utf-8", "replace")
+        if rc > 0:
+            raise RuntimeError(f"{what}: hipError {rc}: {msg}")
+        raise ValueError(f"{what}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -> C.c_void_p:
+    """device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def expect_shape(t: torch.Tensor, shape, name: str):
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")

@@ -1,0 +1,227 @@
+// Batched reset (one thread per environment; executed once per rollout) and the N(0,1) noise generator.
+//
+// Reference arithmetic replaced (file:line relative to /root/reference):
+//   LidarEnv.reset              dgppo/env/lidar_env/base.py:89-124
+//   LidarBicycleTarget.reset    dgppo/env/lidar_env/lidar_bicycle_target.py:60-90
+//   MPE.reset                   dgppo/env/mpe/base.py:81-127
+//   get_node_goal_rng           dgppo/env/utils.py:139-244  (sequential rejection sampling, <=1024 tries, restart)
+//   Rectangle.create / inside   dgppo/env/obstacle.py:39-72
+// RNG: Philox-4x32-10, draw d of env with seed s = Philox(counter=(d,0,0,0), key=(lo32 s, hi32 s)), words 0,1
+// -> two uniforms in [0,1) (same stream as oracle/env_np.py; JAX's threefry keys cannot be reproduced).
+// Built with -ffp-contract=off like env_step.hip.
+#include "common.h"
+
+struct ResetArgs {
+  dgppo_env_cfg cfg;
+  const uint64_t* seeds;
+  float* agent;
+  float* goal;
+  float* obst;
+  int B;
+};
+
+struct Stream {
+  uint32_t k0, k1, d;
+  __device__ inline void uniform2(float& u0, float& u1) {
+    Philox4 p = philox4x32_10(d, 0u, 0u, 0u, k0, k1);
+    d += 1;
+    u0 = u01_from_u32(p.v[0]);
+    u1 = u01_from_u32(p.v[1]);
+  }
+};
+
+__device__ inline bool rect_inside_r(const float* rec, float px, float py, float r) {
+  float rel_x = px - rec[0];
+  float rel_y = py - rec[1];
+  float c = rec[5], s = rec[6];
+  float rel_xx = fabsf(rel_x * c + rel_y * s) - rec[2] / 2.0f;
+  float rel_yy = fabsf(rel_x * s - rel_y * c) - rec[3] / 2.0f;
+  bool is_in_down = (rel_xx < r) && (rel_yy < 0.0f);
+  bool is_in_up = (rel_xx < 0.0f) && (rel_yy < r);
+  bool is_out_corner = (rel_xx > 0.0f) && (rel_yy > 0.0f);
+  bool is_in_circle = sqrtf(rel_xx * rel_xx + rel_yy * rel_yy) < r;
+  return is_in_down || is_in_up || (is_out_corner && is_in_circle);
+}
+
+#define MAX_AGENTS 64
+
+__global__ void env_reset_kernel(ResetArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const dgppo_env_cfg& c = a.cfg;
+  const int n = c.n_agents, no = c.n_obs, SD = c.state_dim;
+  const bool lidar = cfg_is_lidar(c), bicycle = cfg_is_bicycle(c);
+  const float A = c.area_size;
+  const uint64_t seed = a.seeds[b];
+  Stream st;
+  st.k0 = (uint32_t)seed;
+  st.k1 = (uint32_t)(seed >> 32);
+  st.d = 0;
+  float* agent = a.agent + (size_t)b * n * SD;
+  float* goal = a.goal + (size_t)b * n * SD;
+  float* obst = a.obst ? a.obst + (size_t)b * no * cfg_obst_stride(c) : nullptr;
+  const float PI_F = 3.14159265358979323846f;
+  const float TWO_PI_F = 6.28318530717958647692f;
+
+  if (lidar) {
+    for (int o = 0; o < no; ++o) {  // lidar_env/base.py:96-108
+      float u0, u1;
+      st.uniform2(u0, u1);
+      float cx = u0 * A, cy = u1 * A;
+      st.uniform2(u0, u1);
+      const float lo = 0.1f, hi = 0.3f;
+      float w = lo + u0 * (hi - lo);
+      float h = lo + u1 * (hi - lo);
+      st.uniform2(u0, u1);
+      float th = u0 * TWO_PI_F;
+      if (bicycle) th = th - PI_F;
+      float cs = cosf(th), sn = sinf(th);
+      float* rec = obst + o * DGPPO_RECT_STRIDE;
+      rec[0] = cx; rec[1] = cy; rec[2] = w; rec[3] = h; rec[4] = th; rec[5] = cs; rec[6] = sn; rec[7] = 0.0f;
+      float hw = w / 2.0f, hh = h / 2.0f;
+      float bx[4] = {hw, -hw, -hw, hw};
+      float by[4] = {hh, hh, -hh, -hh};
+      for (int m = 0; m < 4; ++m) {  // obstacle.py:40-54
+        rec[8 + 2 * m] = (cs * bx[m] + (-sn) * by[m]) + cx;
+        rec[9 + 2 * m] = (sn * bx[m] + cs * by[m]) + cy;
+      }
+    }
+  }
+  const float min_dist = c.reset_min_dist;
+  const float half = min_dist / 2.0f;
+  const int max_iter = 1024;
+  float sx[MAX_AGENTS], sy[MAX_AGENTS], gx[MAX_AGENTS], gy[MAX_AGENTS];
+  // bounded restarts: every wave reaches the exit (a scene that fails 64 times keeps its last draw)
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    for (int i = 0; i < n; ++i) { sx[i] = 0.0f; sy[i] = 0.0f; gx[i] = 0.0f; gy[i] = 0.0f; }
+    bool failed = false;
+    for (int i = 0; i < n && !failed; ++i) {
+      int it_a = 0, it_g = 0;
+      float cx = 0.0f, cy = 0.0f;
+      for (;;) {
+        float u0, u1;
+        st.uniform2(u0, u1);
+        cx = u0 * A; cy = u1 * A;
+        float dmin = 3.4e38f;
+        for (int j = 0; j < n; ++j) {
+          float dx = sx[j] - cx, dy = sy[j] - cy;
+          dmin = fminf(dmin, sqrtf(dx * dx + dy * dy));
+        }
+        bool inside = false;
+        if (lidar)
+          for (int o = 0; o < no; ++o) inside = inside || rect_inside_r(obst + o * DGPPO_RECT_STRIDE, cx, cy, half);
+        bool ok = !(dmin <= min_dist) && !inside;
+        if (ok || it_a >= max_iter) break;
+        it_a += 1;
+      }
+      sx[i] = cx; sy[i] = cy;
+      for (;;) {
+        float u0, u1;
+        st.uniform2(u0, u1);
+        cx = u0 * A; cy = u1 * A;
+        float dmin = 3.4e38f;
+        for (int j = 0; j < n; ++j) {
+          float dx = gx[j] - cx, dy = gy[j] - cy;
+          dmin = fminf(dmin, sqrtf(dx * dx + dy * dy));
+        }
+        bool inside = false;
+        if (lidar)
+          for (int o = 0; o < no; ++o) inside = inside || rect_inside_r(obst + o * DGPPO_RECT_STRIDE, cx, cy, half);
+        bool ok = !(dmin <= min_dist) && !inside;
+        if (ok || it_g >= max_iter) break;
+        it_g += 1;
+      }
+      gx[i] = cx; gy[i] = cy;
+      if (it_a >= max_iter || it_g >= max_iter) failed = true;
+    }
+    if (!failed) break;
+  }
+  for (int i = 0; i < n; ++i) {
+    for (int d = 0; d < SD; ++d) { agent[i * SD + d] = 0.0f; goal[i * SD + d] = 0.0f; }
+    agent[i * SD] = sx[i]; agent[i * SD + 1] = sy[i];
+    goal[i * SD] = gx[i]; goal[i * SD + 1] = gy[i];
+  }
+  if (bicycle) {  // lidar_bicycle_target.py:80-83
+    for (int i = 0; i < n; ++i) {
+      float u0, u1;
+      st.uniform2(u0, u1);
+      float th = u0 * TWO_PI_F;
+      agent[i * SD + 2] = cosf(th);
+      agent[i * SD + 3] = sinf(th);
+    }
+  }
+  if (!lidar) {  // mpe/base.py:93-118
+    const float lo = c.car_radius * 3.0f;
+    const float hi = A - c.car_radius * 3.0f;
+    const float thr_g = c.two_car_radius + c.obs_radius;
+    for (int o = 0; o < no; ++o) {
+      bool first = true;
+      float cx = 0.0f, cy = 0.0f;
+      for (int it = 0; it < 100000; ++it) {
+        float u0, u1;
+        st.uniform2(u0, u1);
+        if (first) { cx = u0 * A; cy = u1 * A; first = false; }
+        else { cx = lo + u0 * (hi - lo); cy = lo + u1 * (hi - lo); }
+        float da = 3.4e38f, dg = 3.4e38f;
+        for (int j = 0; j < n; ++j) {
+          float dx = sx[j] - cx, dy = sy[j] - cy;
+          da = fminf(da, sqrtf(dx * dx + dy * dy));
+          dx = gx[j] - cx; dy = gy[j] - cy;
+          dg = fminf(dg, sqrtf(dx * dx + dy * dy));
+        }
+        bool bad = (da <= c.car_plus_obs) || (dg <= thr_g) || (cx < lo) || (cy < lo) || (cx > hi) || (cy > hi);
+        if (!bad) break;
+      }
+      for (int d = 0; d < SD; ++d) obst[o * SD + d] = 0.0f;
+      obst[o * SD] = cx; obst[o * SD + 1] = cy;
+    }
+  }
+}
+
+extern "C" int32_t dgppo_env_reset(const dgppo_env_cfg* cfg, const uint64_t* seeds, float* agent, float* goal, float* obst,
+                                   int32_t B, void* stream) {
+  int32_t rc = dgppo_validate_cfg(cfg);
+  if (rc) return rc;
+  DGPPO_REQUIRE(B >= 0, "B must be >= 0");
+  if (B == 0) return 0;
+  DGPPO_REQUIRE(seeds && agent && goal, "seeds/agent/goal must not be NULL");
+  DGPPO_REQUIRE(cfg->n_obs == 0 || obst, "obst must not be NULL when n_obs > 0");
+  DGPPO_REQUIRE(cfg->n_agents <= MAX_AGENTS, "reset supports at most %d agents", MAX_AGENTS);
+  ResetArgs a;
+  a.cfg = *cfg; a.seeds = seeds; a.agent = agent; a.goal = goal; a.obst = obst; a.B = B;
+  hipLaunchKernelGGL(env_reset_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- N(0,1) noise: Philox + Box-Muller; element i uses counter (lo32(off+i/4), hi32(off+i/4), 0, 1) ----------------
+__global__ void randn_kernel(uint64_t seed, uint64_t offset, float* out, int64_t n_elem) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one Philox block -> 4 normals
+  if (q * 4 >= n_elem) return;
+  const uint64_t ctr = offset + (uint64_t)q;
+  Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 1u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // u1 in (0,1], u2 in [0,1)
+    float u1 = ((float)(p.v[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u2 = u01_from_u32(p.v[2 * h + 1]);
+    float r = sqrtf(-2.0f * logf(u1));
+    float s, cth;
+    sincosf(6.28318530717958647692f * u2, &s, &cth);
+    z[2 * h] = r * cth;
+    z[2 * h + 1] = r * s;
+  }
+  for (int j = 0; j < 4; ++j)
+    if (q * 4 + j < n_elem) out[q * 4 + j] = z[j];
+}
+
+extern "C" int32_t dgppo_randn(uint64_t seed, uint64_t offset, float* out, int64_t n_elem, void* stream) {
+  DGPPO_REQUIRE(n_elem >= 0, "n_elem must be >= 0");
+  if (n_elem == 0) return 0;
+  DGPPO_REQUIRE(out, "out must not be NULL");
+  const int64_t quads = (n_elem + 3) / 4;
+  hipLaunchKernelGGL(randn_kernel, dim3(cdiv(quads, 256)), dim3(256), 0, (hipStream_t)stream, seed, offset, out, n_elem);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,148 @@
+/*
+ * dgppo_hip.h — C ABI of libdgppo_hip.so, the MI355X (gfx950) implementation of
+ * DGPPO's data-parallel hot path.
+ *
+ * The reference (syzhang092218-source/dgppo) is pure Python/JAX and has NO FFI
+ * of its own; the boundary it exposes is the Python API (dgppo.env / dgppo.algo /
+ * dgppo.trainer).  This header is therefore the C ABI *underneath* that Python
+ * API: every entry point names the reference function(s) (file:line relative to
+ * /root/reference) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch.Tensor kept
+ *     alive by Python); the library never allocates persistent memory, keeps no
+ *     global mutable state apart from the thread-local error string, and never
+ *     synchronises: all work is enqueued on the caller-supplied hipStream_t
+ *     (passed as void*; NULL = the null stream);
+ *   - all floating point is IEEE fp32, all indices int32, row-major, contiguous;
+ *   - return value: 0 ok, <0 bad argument (see dgppo_last_error()), >0 hipError_t;
+ *   - shapes are passed explicitly and validated on the host before any launch.
+ */
+#ifndef DGPPO_HIP_H
+#define DGPPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGPPO_ABI_VERSION 1
+
+/* environment kinds — dgppo/env/__init__.py:9-23 (registered ids on the hot path) */
+enum {
+  DGPPO_ENV_LIDAR_SPREAD = 0,         /* dgppo/env/lidar_env/lidar_spread.py */
+  DGPPO_ENV_LIDAR_TARGET = 1,         /* dgppo/env/lidar_env/lidar_target.py */
+  DGPPO_ENV_LIDAR_BICYCLE_TARGET = 2, /* dgppo/env/lidar_env/lidar_bicycle_target.py */
+  DGPPO_ENV_MPE_SPREAD = 3,           /* dgppo/env/mpe/mpe_spread.py */
+  DGPPO_ENV_MPE_TARGET = 4            /* dgppo/env/mpe/mpe_target.py */
+};
+
+/* Obstacle record of the LiDAR envs: 16 floats per rectangle
+ * (dgppo/env/obstacle.py:30-56  Rectangle(type, center, width, height, theta, points)):
+ *   [0..1] center  [2] width  [3] height  [4] theta  [5] cos(theta)  [6] sin(theta)  [7] 0
+ *   [8..15] points[4][2]
+ * MPE obstacles are plain state rows [ox, oy, 0, 0] (dgppo/env/mpe/base.py:121).        */
+#define DGPPO_RECT_STRIDE 16
+
+/* Static description of one environment family + PARAMS
+ * (dgppo/env/lidar_env/lidar_spread.py:13-22, dgppo/env/mpe/mpe_spread.py:12-19,
+ *  dgppo/env/__init__.py:29-53).  Thresholds that the reference forms from Python
+ * doubles and then rounds to fp32 are passed pre-rounded so host and device agree. */
+typedef struct dgppo_env_cfg {
+  int32_t kind;        /* DGPPO_ENV_* */
+  int32_t n_agents;    /* n */
+  int32_t n_goals;     /* = n */
+  int32_t n_obs;       /* rectangles (LiDAR) or discs (MPE); may be 0 */
+  int32_t n_rays;      /* R (LiDAR only) */
+  int32_t top_k;       /* k = top_k_rays (LiDAR only) */
+  int32_t state_dim;   /* 4, or 5 for the bicycle */
+  int32_t node_dim;    /* state_dim + 3 */
+  float area_size;
+  float dt;
+  float car_radius;
+  float comm_radius;
+  float obs_radius;        /* MPE only */
+  float dist2goal;
+  float two_car_radius;    /* fp32(2 * car_radius)                       lidar_env/base.py:188 */
+  float lidar_mask_radius; /* fp32(comm_radius - 1e-1)                   lidar_spread.py:88   */
+  float eye_offset;        /* fp32(comm_radius + 1)                      lidar_spread.py:64   */
+  float car_plus_obs;      /* fp32(car_radius + obs_radius)              mpe/base.py:181      */
+  float vel_limit;         /* 0.5 (LiDAR) or 1.0 (MPE)                   state_lim()          */
+  float reset_min_dist;    /* fp32(2.2*car_radius) LiDAR, fp32(2*car_radius) MPE              */
+} dgppo_env_cfg;
+
+/* Optional materialised GraphsTuple (dgppo/utils/graph.py:47-86, GetGraph.to_padded
+ * :212-247).  Any pointer group may be NULL as a whole (all-or-nothing).            */
+typedef struct dgppo_graph_out {
+  float*   nodes;      /* [B, N, node_dim]   */
+  float*   edges;      /* [B, E, 4]          */
+  float*   states;     /* [B, N, state_dim]  */
+  int32_t* receivers;  /* [B, E]             */
+  int32_t* senders;    /* [B, E]             */
+  int32_t* node_type;  /* [B, N]             */
+  int32_t* n_node;     /* [B]                */
+  int32_t* n_edge;     /* [B]                */
+} dgppo_graph_out;
+
+int32_t     dgppo_abi_version(void);
+const char* dgppo_last_error(void);
+
+/* number of nodes N (incl. pad) / edges E of the padded graph — graph.py:212-247 */
+int32_t dgppo_env_num_nodes(const dgppo_env_cfg* cfg);
+int32_t dgppo_env_num_edges(const dgppo_env_cfg* cfg);
+
+/* ---- environment ---------------------------------------------------------------- */
+
+/* One batched env.step: replaces LidarEnv.step (dgppo/env/lidar_env/base.py:151-174),
+ * MPE.step (dgppo/env/mpe/base.py:137-162) and everything they call:
+ *   clip_action/clip_state (env/base.py:80-86), agent_step_euler (lidar_env/base.py:142-149,
+ *   lidar_bicycle_target.py:92-111, mpe/base.py:129-135), get_lidar/raytracing/top-k
+ *   (env/utils.py:49-55,115-136; obstacle.py:62-105), get_reward (lidar_spread.py:35-52,
+ *   lidar_target.py:35-52, mpe_spread.py:32-49, mpe_target.py:32-49), get_cost
+ *   (lidar_env/base.py:180-207, mpe/base.py:164-191), edge_blocks + get_graph + to_padded.
+ *
+ *   agent      [B, n, sd]   state at t
+ *   action     [B, n, 2]    raw action (clipped inside).  NULL => "sense only": no dynamics,
+ *                           no reward/cost; next_agent := agent (used by reset to build graph_0)
+ *   goal       [B, ng, sd]
+ *   obst       LiDAR: [B, n_obs, 16] rectangle records; MPE: [B, n_obs, sd]; may be NULL iff n_obs==0
+ *   hits       LiDAR: [B, n, k, 2] hit points of the graph at t (obstacle cost reads them,
+ *                           lidar_env/base.py:194-197); NULL for MPE / n_obs==0 / sense-only
+ *   ray_cos/ray_sin [R]     cos/sin(linspace(-pi, pi-2pi/R, R)) (env/utils.py:51), fp32
+ *   next_agent [B, n, sd]   out
+ *   next_hits  [B, n, k, 2] out (LiDAR)
+ *   reward     [B]          out (reward of step t, on the pre-step graph)
+ *   cost       [B, n, 2]    out
+ *   gout       optional materialised graph at t+1                                        */
+int32_t dgppo_env_step(const dgppo_env_cfg* cfg,
+                       const float* agent, const float* action, const float* goal,
+                       const float* obst, const float* hits,
+                       const float* ray_cos, const float* ray_sin,
+                       float* next_agent, float* next_hits, float* reward, float* cost,
+                       const dgppo_graph_out* gout, int32_t B, void* stream);
+
+/* Materialise the GraphsTuple of a stored compact record (lazy rollout.graph view):
+ * same arithmetic as get_graph (lidar_env/base.py:227-271, mpe/base.py:211-241).     */
+int32_t dgppo_graph_materialize(const dgppo_env_cfg* cfg,
+                                const float* agent, const float* goal,
+                                const float* obst, const float* hits,
+                                const dgppo_graph_out* gout, int32_t B, void* stream);
+
+/* Batched reset: replaces LidarEnv.reset (lidar_env/base.py:89-124), LidarBicycleTarget.reset
+ * (lidar_bicycle_target.py:60-90), MPE.reset (mpe/base.py:81-127), get_node_goal_rng
+ * (env/utils.py:139-244), Rectangle.create (obstacle.py:39-56).  Philox-4x32-10 counter RNG
+ * keyed by seeds[b] (the JAX threefry stream cannot be reproduced).
+ *   seeds [B] uint64;  out: agent [B,n,sd], goal [B,ng,sd], obst (layout as above).      */
+int32_t dgppo_env_reset(const dgppo_env_cfg* cfg, const uint64_t* seeds,
+                        float* agent, float* goal, float* obst, int32_t B, void* stream);
+
+/* Standard-normal noise: Philox-4x32-10 + Box-Muller, out[i] for i<n_elem; replaces the
+ * jax.random draw inside dist.sample(seed=key) (algo/module/policy.py:196-203).         */
+int32_t dgppo_randn(uint64_t seed, uint64_t offset, float* out, int64_t n_elem, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGPPO_HIP_H */

@@ -1,0 +1,68 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/*.h declares,
+and argument validation fails loudly without touching a GPU."""
+import ctypes as C
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(dgppo_[a-z0-9_]+)\s*\(", src):
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def test_library_loads_and_exports_all_declared_symbols():
+    from dgppo_amd import _native as N
+    lib = N.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 8
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+    assert lib.dgppo_abi_version() == N.ABI_VERSION
+
+
+def test_cfg_struct_matches_header_and_sizes():
+    from dgppo_amd import _native as N
+    assert C.sizeof(N.EnvCfg) == 8 * 4 + 12 * 4
+    cfg = N.make_env_cfg(0, 8, 3)
+    lib = N.lib()
+    lib.dgppo_env_num_nodes.restype = C.c_int32
+    lib.dgppo_env_num_edges.restype = C.c_int32
+    assert lib.dgppo_env_num_nodes(C.byref(cfg)) == 81 == cfg.num_nodes
+    assert lib.dgppo_env_num_edges(C.byref(cfg)) == 192 == cfg.num_edges
+    cfg5 = N.make_env_cfg(2, 16, 8)
+    assert lib.dgppo_env_num_nodes(C.byref(cfg5)) == 161 and lib.dgppo_env_num_edges(C.byref(cfg5)) == 400
+    cfg2 = N.make_env_cfg(3, 3, 3)
+    assert lib.dgppo_env_num_nodes(C.byref(cfg2)) == 10 and lib.dgppo_env_num_edges(C.byref(cfg2)) == 27
+    cfg1 = N.make_env_cfg(4, 3, 0)
+    assert lib.dgppo_env_num_nodes(C.byref(cfg1)) == 7 and lib.dgppo_env_num_edges(C.byref(cfg1)) == 12
+
+
+def test_bad_arguments_are_rejected_before_launch():
+    from dgppo_amd import _native as N
+    lib = N.lib()
+    cfg = N.make_env_cfg(0, 8, 3)
+    cfg.kind = 17
+    lib.dgppo_env_num_nodes.restype = C.c_int32
+    assert lib.dgppo_env_num_nodes(C.byref(cfg)) == -1
+    assert b"unknown env kind" in lib.dgppo_last_error()
+    cfg = N.make_env_cfg(0, 8, 3)
+    rc = lib.dgppo_env_step(C.byref(cfg), None, None, None, None, None, None, None, None, None, None, None, None,
+                            C.c_int32(4), None)
+    assert rc == -1 and b"NULL" in lib.dgppo_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from dgppo_amd import _native as N
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        N.ptr(torch.zeros(3))

@@ -1,0 +1,205 @@
+"""GPU parity: dgppo_env_step / dgppo_env_reset / dgppo_graph_materialize (HIP, through the C ABI) vs oracle/env_np.py.
+Double-integrator and MPE families are bit-exact (kernels built with -ffp-contract=off); the bicycle's dynamics use
+device atan2/sin/cos and are compared within 1e-6, after which sensing/graph on identical states is bit-exact again."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import env_np as E
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+CASES = [
+    ("LidarSpread", 8, 3), ("LidarSpread", 3, 1), ("LidarTarget", 4, 2), ("LidarSpread", 2, 0),
+    ("MPESpread", 3, 3), ("MPETarget", 3, 0), ("MPETarget", 3, 3), ("MPESpread", 5, 2),
+]
+
+
+def _mk(kind_name, n, n_obs):
+    from dgppo_amd import _native as N
+    kind = N.ENV_KINDS[kind_name]
+    return N.make_env_cfg(kind, n, n_obs), E.EnvCfg(kind, n_agents=n, n_obs=n_obs)
+
+
+def _random_state(ocfg, B, seed):
+    """random but valid scene: oracle reset for the scene, then random velocities / displaced agents so masks vary."""
+    rng = np.random.default_rng(seed)
+    agent, goal, obst = E.env_reset(ocfg, rng.integers(1, 2 ** 62, size=B))
+    agent = agent.copy()
+    # pull agents towards each other / obstacles for some envs so that radius masks and LiDAR hits trigger
+    agent[:, :, :2] = (agent[:, :, :2] * 0.5 + 0.4).astype(f32)
+    v = ocfg.vel_limit
+    if ocfg.is_bicycle:
+        th = rng.uniform(0, 2 * np.pi, size=agent.shape[:2])
+        agent[..., 2] = np.cos(th)
+        agent[..., 3] = np.sin(th)
+        agent[..., 4] = rng.uniform(-0.5, 0.5, size=agent.shape[:2])
+    else:
+        agent[..., 2:4] = rng.uniform(-v, v, size=agent.shape[:2] + (2,))
+    action = rng.uniform(-1.5, 1.5, size=agent.shape[:2] + (2,)).astype(f32)
+    return agent.astype(f32), goal, obst, action
+
+
+def _to(x, dev):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def _run_step(cfg, ocfg, agent, goal, obst, hits, action, dev, want_graph=True):
+    from dgppo_amd import ops_env as O
+    B, n = agent.shape[:2]
+    rc, rs = O.ray_tables(max(cfg.n_rays, 1), dev) if cfg.is_lidar else (None, None)
+    nx = torch.empty(B, n, cfg.state_dim, device=dev)
+    nh = torch.empty(B, n, cfg.top_k, 2, device=dev) if (cfg.is_lidar and cfg.n_obs > 0) else None
+    rew = torch.empty(B, device=dev)
+    cost = torch.empty(B, n, 2, device=dev)
+    g = O.alloc_graph(cfg, B, dev) if want_graph else None
+    O.env_step(cfg, _to(agent, dev), _to(action, dev), _to(goal, dev), _to(obst, dev), _to(hits, dev), rc, rs,
+               nx, nh, rew if action is not None else None, cost if action is not None else None, g)
+    torch.cuda.synchronize()
+    out = dict(next_agent=nx.cpu().numpy(), next_hits=None if nh is None else nh.cpu().numpy(),
+               reward=rew.cpu().numpy(), cost=cost.cpu().numpy())
+    if g is not None:
+        out["graph"] = {k: v.cpu().numpy() for k, v in g.items()}
+    return out
+
+
+def _assert_graph_equal(got, want):
+    for k in ("receivers", "senders", "node_type", "n_node", "n_edge"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)          # integer outputs: bit-exact
+    for k in ("nodes", "edges", "states"):
+        np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32), err_msg=k)
+
+
+@pytest.mark.parametrize("kind,n,n_obs", CASES)
+def test_step_bit_exact(cuda, kind, n, n_obs):
+    cfg, ocfg = _mk(kind, n, n_obs)
+    B = 64
+    agent, goal, obst, action = _random_state(ocfg, B, seed=hash((kind, n, n_obs)) % 1000)
+    tab = E.ray_table(ocfg.n_rays)
+    hits = None
+    if ocfg.is_lidar and n_obs > 0:
+        hits, _ = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)
+    want = E.env_step(ocfg, agent, goal, obst, hits, action, tab)
+    got = _run_step(cfg, ocfg, agent, goal, obst, hits, action, cuda)
+    np.testing.assert_array_equal(got["next_agent"].view(np.uint32), want["next_agent"].view(np.uint32))
+    np.testing.assert_array_equal(got["reward"].view(np.uint32), want["reward"].view(np.uint32))
+    np.testing.assert_array_equal(got["cost"].view(np.uint32), want["cost"].view(np.uint32))
+    if want["next_hits"] is not None:
+        np.testing.assert_array_equal(got["next_hits"].view(np.uint32), want["next_hits"].view(np.uint32))
+    _assert_graph_equal(got["graph"], want["graph"])
+    # masks must actually vary in this test, otherwise it proves little
+    r = want["graph"]["receivers"]
+    pad = ocfg.num_nodes - 1
+    assert (r == pad).any() and (r[:, :n * n] != pad).any()
+
+
+def test_bicycle_dynamics_tolerance_then_exact_sensing(cuda):
+    cfg, ocfg = _mk("LidarBicycleTarget", 16, 8)
+    B = 32
+    agent, goal, obst, action = _random_state(ocfg, B, seed=7)
+    tab = E.ray_table(32)
+    hits, _ = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)
+    want = E.env_step(ocfg, agent, goal, obst, hits, action, tab)
+    got = _run_step(cfg, ocfg, agent, goal, obst, hits, action, cuda)
+    np.testing.assert_allclose(got["next_agent"], want["next_agent"], atol=1e-6, rtol=0)   # device atan2/sincos
+    np.testing.assert_array_equal(got["cost"], want["cost"])
+    np.testing.assert_array_equal(got["reward"], want["reward"])
+    # sense-only on the DEVICE's next state: everything downstream is bit-exact again
+    nx = got["next_agent"]
+    h2, _ = E.lidar_sense(ocfg, nx[..., :2], obst, *tab)
+    g2 = E.get_graph(ocfg, nx, goal, obst, h2)
+    np.testing.assert_array_equal(got["next_hits"].view(np.uint32), h2.view(np.uint32))
+    _assert_graph_equal(got["graph"], g2)
+    assert got["graph"]["nodes"].shape == (B, 161, 8) and got["graph"]["edges"].shape == (B, 400, 4)
+
+
+def test_sense_only_and_materialize(cuda):
+    from dgppo_amd import ops_env as O
+    cfg, ocfg = _mk("LidarSpread", 8, 3)
+    B = 16
+    agent, goal, obst, _ = _random_state(ocfg, B, seed=3)
+    tab = E.ray_table(32)
+    got = _run_step(cfg, ocfg, agent, goal, obst, None, None, cuda)
+    h, _ = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)
+    np.testing.assert_array_equal(got["next_agent"], agent)
+    np.testing.assert_array_equal(got["next_hits"].view(np.uint32), h.view(np.uint32))
+    _assert_graph_equal(got["graph"], E.get_graph(ocfg, agent, goal, obst, h))
+    g = O.alloc_graph(cfg, B, cuda)
+    O.graph_materialize(cfg, _to(agent, cuda), _to(goal, cuda), _to(obst, cuda), _to(h, cuda), g)
+    torch.cuda.synchronize()
+    _assert_graph_equal({k: v.cpu().numpy() for k, v in g.items()}, E.get_graph(ocfg, agent, goal, obst, h))
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [("LidarSpread", 8, 3), ("LidarBicycleTarget", 4, 3), ("MPESpread", 3, 3),
+                                           ("MPETarget", 3, 0)])
+def test_reset_matches_oracle_stream(cuda, kind, n, n_obs):
+    from dgppo_amd import ops_env as O
+    cfg, ocfg = _mk(kind, n, n_obs)
+    B = 48
+    seeds = (np.arange(B, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+    seeds_t = torch.from_numpy(seeds.view(np.int64)).to(cuda)
+    agent = torch.empty(B, n, cfg.state_dim, device=cuda)
+    goal = torch.empty(B, n, cfg.state_dim, device=cuda)
+    obst = torch.empty(B, n_obs, cfg.obst_stride, device=cuda) if n_obs > 0 else None
+    O.env_reset(cfg, seeds_t, agent, goal, obst)
+    torch.cuda.synchronize()
+    wa, wg, wo = E.env_reset(ocfg, [int(s) for s in seeds])
+    if kind == "LidarBicycleTarget":
+        np.testing.assert_array_equal(agent.cpu().numpy()[..., :2], wa[..., :2])
+        np.testing.assert_allclose(agent.cpu().numpy(), wa, atol=1e-6)
+    else:
+        np.testing.assert_array_equal(agent.cpu().numpy(), wa)          # integer RNG stream + exact fp32 arithmetic
+    np.testing.assert_array_equal(goal.cpu().numpy(), wg)
+    if n_obs > 0:
+        go = obst.cpu().numpy()
+        if ocfg.is_lidar:
+            np.testing.assert_array_equal(go[..., :5], wo[..., :5])      # centre, w, h, theta from the integer stream
+            np.testing.assert_allclose(go, wo, atol=1e-6)                # cos/sin/points: device trig
+        else:
+            np.testing.assert_array_equal(go, wo)
+
+
+def test_full_size_rollout_properties(cuda):
+    """BASELINE config 3 at full size (4096 envs): 3 chained steps on the device vs the oracle, every output, bit-exact."""
+    from dgppo_amd import ops_env as O
+    cfg, ocfg = _mk("LidarSpread", 8, 3)
+    B, n = 4096, 8
+    rng = np.random.default_rng(0)
+    seeds = rng.integers(1, 2 ** 62, size=B).astype(np.int64)
+    agent = torch.empty(B, n, 4, device=cuda)
+    goal = torch.empty(B, n, 4, device=cuda)
+    obst = torch.empty(B, 3, 16, device=cuda)
+    O.env_reset(cfg, torch.from_numpy(seeds).to(cuda), agent, goal, obst)
+    rc, rs = O.ray_tables(32, cuda)
+    hits = torch.empty(B, n, 8, 2, device=cuda)
+    O.env_step(cfg, agent, None, goal, obst, None, rc, rs, None, hits, None, None, None)
+    a_np, g_np, o_np, h_np = (x.cpu().numpy() for x in (agent, goal, obst, hits))
+    tab = E.ray_table(32)
+    for t in range(3):
+        action = rng.uniform(-1.2, 1.2, size=(B, n, 2)).astype(f32)
+        got = _run_step(cfg, ocfg, a_np, g_np, o_np, h_np, action, cuda)
+        want = E.env_step(ocfg, a_np, g_np, o_np, h_np, action, tab)
+        for k in ("next_agent", "next_hits", "reward", "cost"):
+            np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32), err_msg=f"{k} t={t}")
+        _assert_graph_equal(got["graph"], want["graph"])
+        a_np, h_np = got["next_agent"], got["next_hits"]
+    # size-independent properties
+    g = got["graph"]
+    assert np.all(g["n_node"] == 81) and np.all(g["n_edge"] == 192)
+    assert np.all((g["receivers"] == 80) == (g["senders"] == 80))
+    assert np.all(g["states"][:, 80] == -1)
+
+
+def test_randn_moments_and_determinism(cuda):
+    from dgppo_amd import ops_env as O
+    x = torch.empty(1 << 20, device=cuda)
+    y = torch.empty(1 << 20, device=cuda)
+    O.randn(123, 0, x)
+    O.randn(123, 0, y)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    assert abs(x.mean().item()) < 5e-3 and abs(x.std().item() - 1.0) < 5e-3
+    assert torch.isfinite(x).all()
+    O.randn(124, 0, y)
+    assert not torch.equal(x, y)
