@@ -43,6 +43,34 @@ __device__ inline bool rect_inside_r(const float* rec, float px, float py, float
   return is_in_down || is_in_up || (is_out_corner && is_in_circle);
 }
 
+// One rejection-sampled node (get_node / non_valid_node, env/utils.py:160-172): redraw until it is farther than
+// min_dist from every row of `all` (unfilled rows are zeros) and outside every inflated rectangle, or max_iter tries.
+__device__ __noinline__ void sample_node(Stream& st, float* all, int n, int SD, float A, float min_dist, float half,
+                                         const float* rects, int no, int max_iter, int slot, int& n_iter) {
+  int it = 0;
+  float cx = 0.0f, cy = 0.0f;
+  while (true) {
+    float u0, u1;
+    st.uniform2(u0, u1);
+    cx = u0 * A;
+    cy = u1 * A;
+    float dmin = 3.4e38f;
+    for (int j = 0; j < n; ++j) {
+      float dx = all[j * SD] - cx, dy = all[j * SD + 1] - cy;
+      dmin = fminf(dmin, sqrtf(dx * dx + dy * dy));
+    }
+    bool inside = false;
+    if (rects != nullptr)
+      for (int o = 0; o < no; ++o) inside = inside || rect_inside_r(rects + o * DGPPO_RECT_STRIDE, cx, cy, half);
+    const bool ok = !(dmin <= min_dist) && !inside;
+    if (ok || it >= max_iter) break;
+    it += 1;
+  }
+  all[slot * SD] = cx;
+  all[slot * SD + 1] = cy;
+  n_iter = it;
+}
+
 #define MAX_AGENTS 64
 
 __global__ void env_reset_kernel(ResetArgs a) {
@@ -90,56 +118,19 @@ __global__ void env_reset_kernel(ResetArgs a) {
   const float min_dist = c.reset_min_dist;
   const float half = min_dist / 2.0f;
   const int max_iter = 1024;
-  float sx[MAX_AGENTS], sy[MAX_AGENTS], gx[MAX_AGENTS], gy[MAX_AGENTS];
-  // bounded restarts: every wave reaches the exit (a scene that fails 64 times keeps its last draw)
+  // The output rows double as the working arrays all_states / all_goals of get_node_goal_rng
+  // (env/utils.py:150-151): zero rows included, so the origin's neighbourhood is excluded as in the reference.
+  // bounded restarts: every thread reaches the exit (a scene that fails 64 times keeps its last draw)
   for (int attempt = 0; attempt < 64; ++attempt) {
-    for (int i = 0; i < n; ++i) { sx[i] = 0.0f; sy[i] = 0.0f; gx[i] = 0.0f; gy[i] = 0.0f; }
+    for (int i = 0; i < n * SD; ++i) { agent[i] = 0.0f; goal[i] = 0.0f; }
     bool failed = false;
-    for (int i = 0; i < n && !failed; ++i) {
+    for (int i = 0; i < n; ++i) {
       int it_a = 0, it_g = 0;
-      float cx = 0.0f, cy = 0.0f;
-      for (;;) {
-        float u0, u1;
-        st.uniform2(u0, u1);
-        cx = u0 * A; cy = u1 * A;
-        float dmin = 3.4e38f;
-        for (int j = 0; j < n; ++j) {
-          float dx = sx[j] - cx, dy = sy[j] - cy;
-          dmin = fminf(dmin, sqrtf(dx * dx + dy * dy));
-        }
-        bool inside = false;
-        if (lidar)
-          for (int o = 0; o < no; ++o) inside = inside || rect_inside_r(obst + o * DGPPO_RECT_STRIDE, cx, cy, half);
-        bool ok = !(dmin <= min_dist) && !inside;
-        if (ok || it_a >= max_iter) break;
-        it_a += 1;
-      }
-      sx[i] = cx; sy[i] = cy;
-      for (;;) {
-        float u0, u1;
-        st.uniform2(u0, u1);
-        cx = u0 * A; cy = u1 * A;
-        float dmin = 3.4e38f;
-        for (int j = 0; j < n; ++j) {
-          float dx = gx[j] - cx, dy = gy[j] - cy;
-          dmin = fminf(dmin, sqrtf(dx * dx + dy * dy));
-        }
-        bool inside = false;
-        if (lidar)
-          for (int o = 0; o < no; ++o) inside = inside || rect_inside_r(obst + o * DGPPO_RECT_STRIDE, cx, cy, half);
-        bool ok = !(dmin <= min_dist) && !inside;
-        if (ok || it_g >= max_iter) break;
-        it_g += 1;
-      }
-      gx[i] = cx; gy[i] = cy;
-      if (it_a >= max_iter || it_g >= max_iter) failed = true;
+      sample_node(st, agent, n, SD, A, min_dist, half, lidar ? obst : nullptr, no, max_iter, i, it_a);
+      sample_node(st, goal, n, SD, A, min_dist, half, lidar ? obst : nullptr, no, max_iter, i, it_g);
+      if (it_a >= max_iter || it_g >= max_iter) { failed = true; break; }
     }
     if (!failed) break;
-  }
-  for (int i = 0; i < n; ++i) {
-    for (int d = 0; d < SD; ++d) { agent[i * SD + d] = 0.0f; goal[i * SD + d] = 0.0f; }
-    agent[i * SD] = sx[i]; agent[i * SD + 1] = sy[i];
-    goal[i * SD] = gx[i]; goal[i * SD + 1] = gy[i];
   }
   if (bicycle) {  // lidar_bicycle_target.py:80-83
     for (int i = 0; i < n; ++i) {
@@ -164,9 +155,9 @@ __global__ void env_reset_kernel(ResetArgs a) {
         else { cx = lo + u0 * (hi - lo); cy = lo + u1 * (hi - lo); }
         float da = 3.4e38f, dg = 3.4e38f;
         for (int j = 0; j < n; ++j) {
-          float dx = sx[j] - cx, dy = sy[j] - cy;
+          float dx = agent[j * SD] - cx, dy = agent[j * SD + 1] - cy;
           da = fminf(da, sqrtf(dx * dx + dy * dy));
-          dx = gx[j] - cx; dy = gy[j] - cy;
+          dx = goal[j * SD] - cx; dy = goal[j * SD + 1] - cy;
           dg = fminf(dg, sqrtf(dx * dx + dy * dy));
         }
         bool bad = (da <= c.car_plus_obs) || (dg <= thr_g) || (cx < lo) || (cy < lo) || (cx > hi) || (cy > hi);

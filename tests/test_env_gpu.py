@@ -145,6 +145,12 @@ def test_reset_matches_oracle_stream(cuda, kind, n, n_obs):
     O.env_reset(cfg, seeds_t, agent, goal, obst)
     torch.cuda.synchronize()
     wa, wg, wo = E.env_reset(ocfg, [int(s) for s in seeds])
+    bad = np.nonzero((agent.cpu().numpy()[..., :2] != wa[..., :2]).any(axis=(1, 2)))[0]
+    if len(bad):
+        print("mismatching envs", bad.tolist())
+        for b in bad[:3]:
+            print("env", b, "gpu agent", agent.cpu().numpy()[b, :, :2].tolist(), "oracle", wa[b, :, :2].tolist(),
+                  "gpu goal", goal.cpu().numpy()[b, :, :2].tolist(), "oracle", wg[b, :, :2].tolist())
     if kind == "LidarBicycleTarget":
         np.testing.assert_array_equal(agent.cpu().numpy()[..., :2], wa[..., :2])
         np.testing.assert_allclose(agent.cpu().numpy(), wa, atol=1e-6)
