@@ -1,0 +1,528 @@
+// Row-wise network pieces (fp32): LayerNorm+ReLU, GRU scan (MFMA recurrent product), tanh-Normal head, agent mean-pool,
+// PPO / value losses — forward and hand-written backward.
+//
+// Reference arithmetic replaced (file:line relative to /root/reference):
+//   MLP block Dense->LayerNorm->ReLU     dgppo/nn/mlp.py:17-29 (flax nn.LayerNorm, eps 1e-6, fast variance)
+//   RNN / flax GRUCell                   dgppo/nn/rnn.py:14-30
+//   TanhNormal head + distribution       dgppo/algo/module/policy.py:62-74,191-212 ; distribution.py:10-46
+//   RStateFn mean pool                   dgppo/algo/module/value.py:31-33
+//   losses                               dgppo/algo/informarl.py:374,428-438 ; dgppo/algo/dgppo.py:310
+//   backward = jax.grad of the above     dgppo/algo/informarl.py:377,440 ; dgppo/algo/dgppo.py:316
+#include "common.h"
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm(64) + ReLU: one wave per row (lane = column)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ln_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ stats, int M) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  const float g = gamma[lane], b = beta[lane];
+  for (int row = wave; row < M; row += nw) {
+    const float v = x[(size_t)row * 64 + lane];
+    const float mean = wave_sum(v) * (1.0f / 64.0f);
+    const float mean2 = wave_sum(v * v) * (1.0f / 64.0f);
+    const float var = fmaxf(mean2 - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + 1e-6f);
+    const float o = (v - mean) * rstd * g + b;
+    y[(size_t)row * 64 + lane] = fmaxf(o, 0.0f);
+    if (stats != nullptr && lane == 0) {
+      stats[(size_t)row * 2] = mean;
+      stats[(size_t)row * 2 + 1] = rstd;
+    }
+  }
+}
+
+// dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dy * (y > 0) * gamma
+__global__ void __launch_bounds__(256) ln_relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nw = (gridDim.x * blockDim.x) >> 6;
+  const float g = gamma[lane];
+  float dg = 0.0f, db = 0.0f;
+  for (int row = wave; row < M; row += nw) {
+    const size_t o = (size_t)row * 64 + lane;
+    const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
+    const float xhat = (x[o] - mean) * rstd;
+    const float dyl = (y[o] > 0.0f) ? dy[o] : 0.0f;
+    dg += dyl * xhat;
+    db += dyl;
+    const float dxh = dyl * g;
+    const float m1 = wave_sum(dxh) * (1.0f / 64.0f);
+    const float m2 = wave_sum(dxh * xhat) * (1.0f / 64.0f);
+    dx[o] = rstd * (dxh - m1 - xhat * m2);
+  }
+  atomicAdd(dgamma + lane, dg);
+  atomicAdd(dbeta + lane, db);
+}
+
+extern "C" int32_t dgppo_ln_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                     int32_t M, void* stream) {
+  DGPPO_REQUIRE(M >= 0, "ln_relu_fwd: M < 0");
+  if (M == 0) return 0;
+  DGPPO_REQUIRE(x && gamma && beta && y, "ln_relu_fwd: NULL operand");
+  const int grid = min(cdiv(M, 4), 2048);
+  hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats, M);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t dgppo_ln_relu_bwd(const float* x, const float* y, const float* stats, const float* gamma,
+                                     const float* dy, float* dx, float* dgamma, float* dbeta, int32_t M, void* stream) {
+  DGPPO_REQUIRE(M >= 0, "ln_relu_bwd: M < 0");
+  if (M == 0) return 0;
+  DGPPO_REQUIRE(x && y && stats && gamma && dy && dx && dgamma && dbeta, "ln_relu_bwd: NULL operand");
+  const int grid = min(cdiv(M, 4), 1024);
+  hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma, dy, dx, dgamma,
+                     dbeta, M);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GRU scan.  Sequence s (0 <= s < n_seq) at step tau lives in row  ((s / n_inner) * T + tau) * n_inner + (s % n_inner)
+// of every [rows, *] activation matrix (n_inner = agents per graph, so graphs are ordered (env, time) and a chunk of T
+// consecutive graphs of one env forms the time axis).  gi = x W_i + b_i is precomputed for all rows by the dense kernel.
+//   r = sig(gi_r + h Whr)  z = sig(gi_z + h Whz)  n = tanh(gi_n + r * (h Whn + bhn))  h' = (1 - z) n + z h
+// ---------------------------------------------------------------------------------------------------------------------
+#define GRU_H 64
+#define GRU_SEQ 64   // sequences per workgroup
+#define GRU_WL 193   // padded LDS row of Wh
+#define GRU_HL 65    // padded LDS row of h
+
+struct GruArgs {
+  const float* gi;      // [rows, 192]
+  const float* Wh;      // [64, 192]  (cols r | z | n)
+  const float* bhn;     // [64]
+  const float* h0;      // [n_seq, 64] or NULL (zeros)
+  float* hs;            // [rows, 64]  h after each step
+  float* hprev;         // [rows, 64]  h before each step (saved for backward) or NULL
+  float* gates;         // [rows, 256] r | z | n | hn_lin (saved for backward) or NULL
+  // backward
+  const float* dhs;     // [rows, 64] gradient w.r.t. every step's output
+  float* dgi;           // [rows, 192]
+  float* dgh;           // [rows, 192]  (da_r | da_z | d hn_lin) -> dWh = hprev^T dgh, dbhn = colsum(dgh[:,128:])
+  int n_seq, T, n_inner;
+};
+
+__device__ inline size_t gru_row(const GruArgs& a, int s, int tau) {
+  const int grp = s / a.n_inner, i = s - grp * a.n_inner;
+  return ((size_t)grp * a.T + tau) * a.n_inner + i;
+}
+__device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
+  extern __shared__ float sm[];
+  float* s_w = sm;                       // [64][GRU_WL]
+  float* s_h = s_w + GRU_H * GRU_WL;     // [GRU_SEQ][GRU_HL]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int s0 = blockIdx.x * GRU_SEQ;
+  for (int idx = tid; idx < GRU_H * 192; idx += 256) {
+    const int k = idx / 192, c = idx - k * 192;
+    s_w[k * GRU_WL + c] = a.Wh[idx];
+  }
+  for (int idx = tid; idx < GRU_SEQ * GRU_H; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    const int s = s0 + r;
+    s_h[r * GRU_HL + c] = (a.h0 != nullptr && s < a.n_seq) ? a.h0[(size_t)s * GRU_H + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int tau = 0; tau < a.T; ++tau) {
+    f32x4 acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* hrow = s_h + (wave * 16 + li) * GRU_HL;
+    for (int k0 = 0; k0 < GRU_H; k0 += 4) {
+      const float av = hrow[k0 + lq];
+      const float* wrow = s_w + (k0 + lq) * GRU_WL + li;
+#pragma unroll
+      for (int t = 0; t < 12; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[t * 16], acc[t], 0, 0, 0);
+    }
+    __syncthreads();  // every wave has read its rows of s_h before anyone overwrites them
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int c = tt * 16 + li;
+      const float bn = a.bhn[c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = wave * 16 + lq * 4 + r;
+        const int s = s0 + rl;
+        if (s >= a.n_seq) continue;
+        const size_t row = gru_row(a, s, tau);
+        const float* g = a.gi + row * 192;
+        const float hp = s_h[rl * GRU_HL + c];
+        const float rg = sigmoidf_(g[c] + acc[tt][r]);
+        const float zg = sigmoidf_(g[64 + c] + acc[tt + 4][r]);
+        const float hn = acc[tt + 8][r] + bn;
+        const float ng = tanhf(g[128 + c] + rg * hn);
+        const float hnew = (1.0f - zg) * ng + zg * hp;
+        a.hs[row * GRU_H + c] = hnew;
+        if (a.hprev != nullptr) a.hprev[row * GRU_H + c] = hp;
+        if (a.gates != nullptr) {
+          float* gs = a.gates + row * 256;
+          gs[c] = rg; gs[64 + c] = zg; gs[128 + c] = ng; gs[192 + c] = hn;
+        }
+        s_h[rl * GRU_HL + c] = hnew;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// BPTT: walks tau = T-1 .. 0 carrying dh; the recurrent product dh_prev += dgh * Wh^T runs on the matrix cores.
+__global__ void __launch_bounds__(256) gru_bwd_kernel(GruArgs a) {
+  extern __shared__ float sm[];
+  float* s_w = sm;                        // [64][GRU_WL]   Wh
+  float* s_g = s_w + GRU_H * GRU_WL;      // [GRU_SEQ][GRU_WL]  dgh of this step
+  float* s_dh = s_g + GRU_SEQ * GRU_WL;   // [GRU_SEQ][GRU_HL]  carried dh
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int s0 = blockIdx.x * GRU_SEQ;
+  for (int idx = tid; idx < GRU_H * 192; idx += 256) {
+    const int k = idx / 192, c = idx - k * 192;
+    s_w[k * GRU_WL + c] = a.Wh[idx];
+  }
+  for (int idx = tid; idx < GRU_SEQ * GRU_HL; idx += 256) s_dh[idx] = 0.0f;
+  __syncthreads();
+  for (int tau = a.T - 1; tau >= 0; --tau) {
+    // phase A: gate gradients, elementwise
+    for (int idx = tid; idx < GRU_SEQ * GRU_H; idx += 256) {
+      const int rl = idx >> 6, c = idx & 63;
+      const int s = s0 + rl;
+      float dar = 0.f, daz = 0.f, dan = 0.f, dhn = 0.f, dhz = 0.f;
+      if (s < a.n_seq) {
+        const size_t row = gru_row(a, s, tau);
+        const float* gs = a.gates + row * 256;
+        const float rg = gs[c], zg = gs[64 + c], ng = gs[128 + c], hn = gs[192 + c];
+        const float hp = a.hprev[row * GRU_H + c];
+        const float dh = s_dh[rl * GRU_HL + c] + a.dhs[row * GRU_H + c];
+        const float dz = dh * (hp - ng);
+        const float dn = dh * (1.0f - zg);
+        dan = dn * (1.0f - ng * ng);
+        dhn = dan * rg;
+        dar = dan * hn * rg * (1.0f - rg);
+        daz = dz * zg * (1.0f - zg);
+        dhz = dh * zg;
+        float* o = a.dgi + row * 192;
+        o[c] = dar; o[64 + c] = daz; o[128 + c] = dan;
+        float* p = a.dgh + row * 192;
+        p[c] = dar; p[64 + c] = daz; p[128 + c] = dhn;
+      }
+      s_g[rl * GRU_WL + c] = dar;
+      s_g[rl * GRU_WL + 64 + c] = daz;
+      s_g[rl * GRU_WL + 128 + c] = dhn;
+      s_dh[rl * GRU_HL + c] = dhz;
+    }
+    __syncthreads();
+    // phase B: dh_prev[row, c] += sum_k dgh[row, k] * Wh[c, k]
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* grow = s_g + (wave * 16 + li) * GRU_WL;
+    for (int k0 = 0; k0 < 192; k0 += 4) {
+      const float av = grow[k0 + lq];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float bv = s_w[(t * 16 + li) * GRU_WL + k0 + lq];  // B[k][j] = Wh[j][k]
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_dh[(wave * 16 + lq * 4 + r) * GRU_HL + t * 16 + li] += acc[t][r];
+    __syncthreads();
+  }
+}
+
+static int32_t gru_check(const GruArgs& a) {
+  DGPPO_REQUIRE(a.n_seq >= 0 && a.T >= 1 && a.n_inner >= 1, "gru: bad sizes n_seq=%d T=%d n_inner=%d", a.n_seq, a.T, a.n_inner);
+  DGPPO_REQUIRE(a.n_seq % a.n_inner == 0, "gru: n_seq must be a multiple of n_inner");
+  return 0;
+}
+
+extern "C" int32_t dgppo_gru_fwd(const float* gi, const float* Wh, const float* bhn, const float* h0, float* hs,
+                                 float* hprev, float* gates, int32_t n_seq, int32_t T, int32_t n_inner, void* stream) {
+  GruArgs a{};
+  a.gi = gi; a.Wh = Wh; a.bhn = bhn; a.h0 = h0; a.hs = hs; a.hprev = hprev; a.gates = gates;
+  a.n_seq = n_seq; a.T = T; a.n_inner = n_inner;
+  int32_t rc = gru_check(a);
+  if (rc) return rc;
+  if (n_seq == 0) return 0;
+  DGPPO_REQUIRE(gi && Wh && bhn && hs, "gru_fwd: NULL operand");
+  const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)GRU_SEQ * GRU_HL);
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(n_seq, GRU_SEQ)), dim3(256), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t dgppo_gru_bwd(const float* dhs, const float* Wh, const float* hprev, const float* gates, float* dgi,
+                                 float* dgh, int32_t n_seq, int32_t T, int32_t n_inner, void* stream) {
+  GruArgs a{};
+  a.dhs = dhs; a.Wh = Wh; a.hprev = (float*)hprev; a.gates = (float*)gates; a.dgi = dgi; a.dgh = dgh;
+  a.n_seq = n_seq; a.T = T; a.n_inner = n_inner;
+  int32_t rc = gru_check(a);
+  if (rc) return rc;
+  if (n_seq == 0) return 0;
+  DGPPO_REQUIRE(dhs && Wh && hprev && gates && dgi && dgh, "gru_bwd: NULL operand");
+  const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)GRU_SEQ * GRU_WL + (size_t)GRU_SEQ * GRU_HL);
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(n_seq, GRU_SEQ)), dim3(256), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tanh-Normal head (policy.py:62-74, distribution.py:10-46).  ms[row] = [mean0, mean1, std_trans0, std_trans1]
+// ---------------------------------------------------------------------------------------------------------------------
+#define STD_INIT_INV (-0.43275212956718856f)  // log(exp(0.5) - 1)
+#define STD_MIN 1e-5f
+#define THRESH 0.999f
+#define INV_THRESH 3.8002011672502f           // atanh(0.999)
+#define LOG_EPS (-6.907755278982137f)         // log(1 - 0.999)
+#define HALF_LOG_2PI 0.9189385332046727f
+#define LOG2_F 0.6931471805599453f
+
+__device__ inline float softplusf_(float x) { return (x > 20.0f) ? x : log1pf(expf(x)); }
+// log Phi(z): erfc for the bulk, asymptotic series for the far left tail (tfp special_math.log_ndtr)
+__device__ inline float log_ndtrf_(float z) {
+  if (z > -5.0f) return logf(0.5f * erfcf(-z * 0.70710678118654752f));
+  const float z2 = z * z;
+  const float series = 1.0f - 1.0f / z2 + 3.0f / (z2 * z2) - 15.0f / (z2 * z2 * z2);
+  return -0.5f * z2 - logf(-z) - HALF_LOG_2PI + logf(series);
+}
+// d/dz log Phi(z) = phi(z) / Phi(z)
+__device__ inline float dlog_ndtrf_(float z) {
+  if (z > -5.0f) return 0.3989422804014327f * expf(-0.5f * z * z) / (0.5f * erfcf(-z * 0.70710678118654752f));
+  const float z2 = z * z;
+  return -z / (1.0f - 1.0f / z2 + 3.0f / (z2 * z2));
+}
+__device__ inline float tanh_fldj(float x) { return 2.0f * (LOG2_F - x - softplusf_(-2.0f * x)); }
+
+struct HeadArgs {
+  const float* ms;        // [rows, 4]
+  const float* eps;       // sample: [rows, 2] noise; eval: [n_agents, 2] the constant entropy noise eps_hat
+  const float* action_in; // eval: [rows, 2]
+  float* action;          // sample / mode: [rows, 2]
+  float* log_pi;          // [rows]
+  float* entropy;         // eval: [rows]
+  int rows, n_agents, mode;  // 0 sample, 1 mode, 2 eval
+  // PPO loss + backward (eval only)
+  const float* log_pi_old;   // [rows]
+  const float* adv;          // [rows]
+  float* dms;                // [rows, 4]
+  float* stats;              // [8]: sum loss_policy, sum entropy, sum(l2 > l1), sum |ratio - 1|, ...
+  float clip_eps, coef_ent, inv_count;
+};
+
+__device__ inline float tn_log_prob_dim(float act, float mu, float sd) {
+  const float ac = fminf(fmaxf(act, -THRESH), THRESH);
+  if (ac <= -THRESH) return log_ndtrf_((-INV_THRESH - mu) / sd) - LOG_EPS;
+  if (ac >= THRESH) return log_ndtrf_(-(INV_THRESH - mu) / sd) - LOG_EPS;
+  const float x = atanhf(ac);
+  const float z = (x - mu) / sd;
+  return -0.5f * z * z - logf(sd) - HALF_LOG_2PI - tanh_fldj(x);
+}
+
+__global__ void __launch_bounds__(256) policy_head_kernel(HeadArgs a) {
+  const int row_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = row_raw < a.rows;
+  const int row = valid ? row_raw : a.rows - 1;  // invalid lanes recompute the last row and discard it (keeps waves whole)
+  const float4 m = reinterpret_cast<const float4*>(a.ms)[row];
+  const float mu[2] = {m.x, m.y};
+  const float st[2] = {m.z, m.w};
+  float sd[2];
+  for (int d = 0; d < 2; ++d) sd[d] = softplusf_(st[d] + STD_INIT_INV) + STD_MIN;
+  if (a.mode == 1) {  // PPOPolicy.get_action: tanh(mean)
+    if (valid) {
+      a.action[row * 2] = tanhf(mu[0]);
+      a.action[row * 2 + 1] = tanhf(mu[1]);
+    }
+    return;
+  }
+  float act[2];
+  if (a.mode == 0) {  // sample_action: tanh(mean + std * eps); log_prob recomputes atanh(clip(a)) like the reference
+    for (int d = 0; d < 2; ++d) act[d] = tanhf(mu[d] + sd[d] * a.eps[row * 2 + d]);
+    if (valid) {
+      a.action[row * 2] = act[0];
+      a.action[row * 2 + 1] = act[1];
+      a.log_pi[row] = tn_log_prob_dim(act[0], mu[0], sd[0]) + tn_log_prob_dim(act[1], mu[1], sd[1]);
+    }
+    return;
+  }
+  // eval_action
+  act[0] = a.action_in[row * 2];
+  act[1] = a.action_in[row * 2 + 1];
+  const int ag = row % a.n_agents;
+  float lp = 0.0f, ent = 0.0f;
+  float dlp_dmu[2], dlp_dsd[2], dent_dmu[2], dent_dsd[2];
+  for (int d = 0; d < 2; ++d) {
+    const float ac = fminf(fmaxf(act[d], -THRESH), THRESH);
+    if (ac <= -THRESH) {
+      const float u = (-INV_THRESH - mu[d]) / sd[d];
+      lp += log_ndtrf_(u) - LOG_EPS;
+      const float r = dlog_ndtrf_(u);
+      dlp_dmu[d] = -r / sd[d];
+      dlp_dsd[d] = -r * u / sd[d];
+    } else if (ac >= THRESH) {
+      const float u = (mu[d] - INV_THRESH) / sd[d];
+      lp += log_ndtrf_(u) - LOG_EPS;
+      const float r = dlog_ndtrf_(u);
+      dlp_dmu[d] = r / sd[d];
+      dlp_dsd[d] = -r * u / sd[d];
+    } else {
+      const float x = atanhf(ac);
+      const float z = (x - mu[d]) / sd[d];
+      lp += -0.5f * z * z - logf(sd[d]) - HALF_LOG_2PI - tanh_fldj(x);
+      dlp_dmu[d] = z / sd[d];
+      dlp_dsd[d] = (z * z - 1.0f) / sd[d];
+    }
+    const float eh = a.eps[ag * 2 + d];
+    const float y = mu[d] + sd[d] * eh;
+    ent += 0.5f + HALF_LOG_2PI + logf(sd[d]) + tanh_fldj(y);
+    const float th = tanhf(y);
+    dent_dmu[d] = -2.0f * th;
+    dent_dsd[d] = 1.0f / sd[d] - 2.0f * th * eh;
+  }
+  if (valid) {
+    a.log_pi[row] = lp;
+    a.entropy[row] = ent;
+  }
+  if (a.dms == nullptr) return;
+  // PPO clipped surrogate (informarl.py:428-435):  mean(max(-rho A, -clip(rho) A)) - coef_ent * mean(H)
+  const float A = a.adv[row];
+  const float rho = expf(lp - a.log_pi_old[row]);
+  const float l1 = -rho * A;
+  const float l2 = -fminf(fmaxf(rho, 1.0f - a.clip_eps), 1.0f + a.clip_eps) * A;
+  const float lsel = fmaxf(l1, l2);
+  const float dl_dlp = ((l2 > l1) ? 0.0f : -rho * A) * a.inv_count;
+  const float dl_dent = -a.coef_ent * a.inv_count;
+  if (valid) {
+    float4 o;
+    const float dsd0 = dl_dlp * dlp_dsd[0] + dl_dent * dent_dsd[0];
+    const float dsd1 = dl_dlp * dlp_dsd[1] + dl_dent * dent_dsd[1];
+    o.x = dl_dlp * dlp_dmu[0] + dl_dent * dent_dmu[0];
+    o.y = dl_dlp * dlp_dmu[1] + dl_dent * dent_dmu[1];
+    o.z = dsd0 * sigmoidf_(st[0] + STD_INIT_INV);  // d softplus
+    o.w = dsd1 * sigmoidf_(st[1] + STD_INIT_INV);
+    reinterpret_cast<float4*>(a.dms)[row] = o;
+  }
+  // diagnostics: wave-level partial sums, one atomic per wave
+  const float vf = valid ? 1.0f : 0.0f;
+  const float s0 = wave_sum(vf * lsel), s1 = wave_sum(vf * ent), s2 = wave_sum((valid && l2 > l1) ? 1.0f : 0.0f),
+              s3 = wave_sum(vf * fabsf(rho - 1.0f));
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(a.stats + 0, s0);
+    atomicAdd(a.stats + 1, s1);
+    atomicAdd(a.stats + 2, s2);
+    atomicAdd(a.stats + 3, s3);
+  }
+}
+
+extern "C" int32_t dgppo_policy_head(const float* ms, const float* eps, const float* action_in, float* action,
+                                     float* log_pi, float* entropy, int32_t rows, int32_t n_agents, int32_t mode,
+                                     const float* log_pi_old, const float* adv, float* dms, float* stats, float clip_eps,
+                                     float coef_ent, void* stream) {
+  DGPPO_REQUIRE(rows >= 0 && n_agents >= 1 && mode >= 0 && mode <= 2, "policy_head: bad arguments");
+  if (rows == 0) return 0;
+  DGPPO_REQUIRE(ms, "policy_head: ms is NULL");
+  DGPPO_REQUIRE(((uintptr_t)ms & 15) == 0, "policy_head: ms must be 16-byte aligned");
+  if (mode == 0) DGPPO_REQUIRE(eps && action && log_pi, "policy_head(sample): NULL operand");
+  if (mode == 1) DGPPO_REQUIRE(action, "policy_head(mode): NULL operand");
+  if (mode == 2) {
+    DGPPO_REQUIRE(eps && action_in && log_pi && entropy, "policy_head(eval): NULL operand");
+    if (dms) DGPPO_REQUIRE(log_pi_old && adv && stats && ((uintptr_t)dms & 15) == 0, "policy_head(eval+loss): NULL operand");
+  }
+  HeadArgs a{};
+  a.ms = ms; a.eps = eps; a.action_in = action_in; a.action = action; a.log_pi = log_pi; a.entropy = entropy;
+  a.rows = rows; a.n_agents = n_agents; a.mode = mode; a.log_pi_old = log_pi_old; a.adv = adv; a.dms = dms; a.stats = stats;
+  a.clip_eps = clip_eps; a.coef_ent = coef_ent; a.inv_count = 1.0f / (float)rows;
+  hipLaunchKernelGGL(policy_head_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// value loss 1/2 (v - target)^2 mean (optax.l2_loss().mean()), gradient and sum
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) value_loss_kernel(const float* __restrict__ v, const float* __restrict__ target,
+                                                         float* __restrict__ dv, float* __restrict__ stats, int count,
+                                                         float inv_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float l = 0.0f;
+  if (i < count) {
+    const float d = v[i] - target[i];
+    dv[i] = d * inv_count;
+    l = 0.5f * d * d;
+  }
+  l = wave_sum(l);
+  if ((threadIdx.x & 63) == 0) atomicAdd(stats, l);
+}
+
+extern "C" int32_t dgppo_value_loss(const float* v, const float* target, float* dv, float* stats, int32_t count,
+                                    void* stream) {
+  DGPPO_REQUIRE(count >= 0, "value_loss: count < 0");
+  if (count == 0) return 0;
+  DGPPO_REQUIRE(v && target && dv && stats, "value_loss: NULL operand");
+  hipLaunchKernelGGL(value_loss_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, v, target, dv, stats,
+                     count, 1.0f / (float)count);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mean over the agents of a graph (value.py:33) and its backward; relu backward; small utilities
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void mean_agents_kernel(const float* __restrict__ x, float* __restrict__ y, int G, int n, int D, int backward) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (backward) {  // x = dP [G, D] -> y = dX [G, n, D]
+    if (idx >= G * n * D) return;
+    const int d = idx % D, g = idx / (n * D);
+    y[idx] = x[(size_t)g * D + d] / (float)n;
+  } else {
+    if (idx >= G * D) return;
+    const int d = idx % D, g = idx / D;
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) acc += x[((size_t)g * n + i) * D + d];
+    y[idx] = acc / (float)n;
+  }
+}
+
+extern "C" int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_t D, int32_t backward,
+                                     void* stream) {
+  DGPPO_REQUIRE(G >= 0 && n >= 1 && D >= 1, "mean_agents: bad sizes");
+  if (G == 0) return 0;
+  DGPPO_REQUIRE(x && y, "mean_agents: NULL operand");
+  const long total = backward ? (long)G * n * D : (long)G * D;
+  hipLaunchKernelGGL(mean_agents_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, G, n, D, backward);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// dx = dy * (y > 0), in place on dy
+__global__ void relu_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count && !(y[i] > 0.0f)) dy[i] = 0.0f;
+}
+
+extern "C" int32_t dgppo_relu_bwd(float* dy, const float* y, int64_t count, void* stream) {
+  DGPPO_REQUIRE(count >= 0, "relu_bwd: count < 0");
+  if (count == 0) return 0;
+  DGPPO_REQUIRE(dy && y, "relu_bwd: NULL operand");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, (long)count);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,431 @@
+// Graph side of the GraphTransformer layer (dgppo/nn/gnn.py:78-117) in per-agent fixed-fan-in form.
+//
+// Only agents receive messages and every sender slot of an agent has a static node id (SURVEY F5/F7;
+// dgppo/utils/graph.py:35-44, dgppo/env/lidar_env/lidar_spread.py:57-96), so jraph.segment_softmax / segment_sum over
+// the flat edge list reduce to a masked softmax over S = n + goal_slots + obs_slots slots per agent.  Masked edges are
+// re-routed pad->pad in the reference and therefore never reach an agent: here they are simply excluded.
+//
+// Algebraic form (same function, different summation order; see DESIGN.md "GNN layer"):
+//   logit[i,s,h] = <q_h(x_i), k_h(x_s)>/sqrt(D) = qt[i,h,:] . x_s + const(i,h)   with qt = x_i Mcat + c   (dense, outside)
+//   sum_s a[i,s,h] (v_h(x_s) + e_h(edge_is)) = (sum_s a[i,s,h] [x_s ; edge_is]) [Wv_h ; We_h] + bv_h   (dense, outside)
+// so this file only does: graph features, logits against RAW sender features, masked softmax, aggregation of raw
+// features, and the matching backward.  const(i,h) (the key bias) cancels in the softmax.
+#include "common.h"
+
+struct Topo {
+  int n, ng, gs, os, per, lidar, spread;  // per = k (LiDAR) or n_obs (MPE)
+  int S, Ns;                              // slots per agent, nodes without pad
+};
+
+static Topo make_topo(const dgppo_env_cfg& c) {
+  Topo t;
+  t.n = c.n_agents; t.ng = c.n_goals; t.gs = cfg_goal_slots(c); t.os = cfg_obs_slots(c);
+  t.lidar = cfg_is_lidar(c) ? 1 : 0; t.spread = cfg_is_spread(c) ? 1 : 0;
+  t.per = t.os;
+  t.S = t.n + t.gs + t.os;
+  t.Ns = t.n + t.ng + cfg_obs_nodes(c);
+  return t;
+}
+
+__device__ inline int sender_node(const Topo& t, int i, int s) {
+  if (s < t.n) return s;
+  if (s < t.n + t.gs) return t.spread ? t.n + (s - t.n) : t.n + i;
+  const int m = s - t.n - t.gs;
+  return t.lidar ? t.n + t.ng + i * t.per + m : t.n + t.ng + m;
+}
+// slot through which node nd sends to agent i (or -1)
+__device__ inline int slot_of(const Topo& t, int nd, int i) {
+  if (nd < t.n) return nd;
+  if (nd < t.n + t.ng) {
+    const int g = nd - t.n;
+    return t.spread ? t.n + g : (g == i ? t.n : -1);
+  }
+  const int q = nd - t.n - t.ng;
+  if (t.lidar) return (q / t.per == i) ? t.n + t.gs + (q - i * t.per) : -1;
+  return t.n + t.gs + q;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// graph features: compact record -> agent/other node feature matrices, per-slot edge features and masks.
+// Same arithmetic (explicit _rn ops = no fma contraction) as env_step.hip phase 5, i.e. as
+// lidar_env/base.py:227-271 + lidar_spread.py:57-96 (+ MPE twins), so masks agree bit for bit with the GraphsTuple.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FeatArgs {
+  dgppo_env_cfg cfg;
+  Topo t;
+  const float* agent; long agent_se, agent_st;   // agent + env*se + time*st  -> [n, sd]
+  const float* goal;                             // goal + env*ng*sd
+  const float* obst;                             // MPE: obst + env*n_obs*sd
+  const float* hits; long hits_se, hits_st;      // LiDAR: hits + env*se + time*st -> [n, k, 2]
+  const int32_t* env_ids;                        // [n_env] or NULL (identity)
+  int n_env, n_time;                             // graphs g = e * n_time + t
+  float* Xa;      // [G*n, Fp]
+  float* Xo;      // [G*(Ns-n), Fp]
+  float* efeat;   // [G*n, S, 4]
+  float* emask;   // [G*n, S]
+  int Fp;
+};
+
+__device__ inline float dist_rn(float dx, float dy) { return __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))); }
+
+template <int SD>
+__global__ void graph_feats_kernel(FeatArgs a) {
+  extern __shared__ float sm[];
+  const dgppo_env_cfg& c = a.cfg;
+  const Topo& t = a.t;
+  const int g = blockIdx.x;
+  const int e = g / a.n_time, tt = g - e * a.n_time;
+  const int env = a.env_ids ? a.env_ids[e] : e;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int n = t.n, ng = t.ng, S = t.S, Fp = a.Fp;
+  const int n_on = t.Ns - n - ng;
+  float* s_ag = sm;                 // n*SD
+  float* s_go = s_ag + n * SD;      // ng*SD
+  float* s_ob = s_go + ng * SD;     // n_on * 2 (positions of hit / obstacle nodes) then MPE extra state
+  float* s_fa = s_ob + n_on * SD;   // n*4
+  float* s_fg = s_fa + n * 4;       // ng*4
+  const float* ag = a.agent + (size_t)env * a.agent_se + (size_t)tt * a.agent_st;
+  for (int i = tid; i < n * SD; i += nt) s_ag[i] = ag[i];
+  for (int i = tid; i < ng * SD; i += nt) s_go[i] = a.goal[(size_t)env * ng * SD + i];
+  if (n_on > 0) {
+    if (t.lidar) {
+      const float* hp = a.hits + (size_t)env * a.hits_se + (size_t)tt * a.hits_st;
+      for (int i = tid; i < n_on * 2; i += nt) {
+        const int q = i >> 1, d = i & 1;
+        s_ob[q * SD + d] = hp[i];
+      }
+      for (int i = tid; i < n_on * (SD - 2); i += nt) {
+        const int q = i / (SD - 2), d = i - q * (SD - 2);
+        s_ob[q * SD + 2 + d] = 0.0f;
+      }
+    } else {
+      for (int i = tid; i < n_on * SD; i += nt) s_ob[i] = a.obst[(size_t)env * n_on * SD + i];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n + ng; i += nt) {
+    const float* s = (i < n) ? s_ag + i * SD : s_go + (i - n) * SD;
+    float* f = (i < n) ? s_fa + i * 4 : s_fg + (i - n) * 4;
+    if constexpr (SD == 5) {
+      f[0] = s[0]; f[1] = s[1]; f[2] = __fmul_rn(s[4], s[2]); f[3] = __fmul_rn(s[4], s[3]);
+    } else {
+      f[0] = s[0]; f[1] = s[1]; f[2] = s[2]; f[3] = s[3];
+    }
+  }
+  __syncthreads();
+  // node feature rows: [state | obs, goal, agent indicator], zero padded to Fp
+  constexpr int ND = SD + 3;
+  for (int idx = tid; idx < t.Ns * Fp; idx += nt) {
+    const int nd = idx / Fp, col = idx - nd * Fp;
+    float v = 0.0f;
+    if (nd < n) v = (col < SD) ? s_ag[nd * SD + col] : ((col == SD + 2) ? 1.0f : 0.0f);
+    else if (nd < n + ng) v = (col < SD) ? s_go[(nd - n) * SD + col] : ((col == SD + 1) ? 1.0f : 0.0f);
+    else v = (col < SD) ? s_ob[(nd - n - ng) * SD + col] : ((col == SD) ? 1.0f : 0.0f);
+    if (col >= ND) v = 0.0f;
+    if (nd < n) a.Xa[((size_t)g * n + nd) * Fp + col] = v;
+    else a.Xo[((size_t)g * (t.Ns - n) + (nd - n)) * Fp + col] = v;
+  }
+  // per-slot edge feature + mask
+  for (int idx = tid; idx < n * S; idx += nt) {
+    const int i = idx / S, s = idx - i * S;
+    float4 f;
+    bool mask;
+    const float* fi = s_fa + i * 4;
+    const float px = s_ag[i * SD], py = s_ag[i * SD + 1];
+    if (s < n) {
+      const float* fj = s_fa + s * 4;
+      f = make_float4(__fsub_rn(fi[0], fj[0]), __fsub_rn(fi[1], fj[1]), __fsub_rn(fi[2], fj[2]), __fsub_rn(fi[3], fj[3]));
+      float d = __fadd_rn(dist_rn(__fsub_rn(px, s_ag[s * SD]), __fsub_rn(py, s_ag[s * SD + 1])), (i == s) ? c.eye_offset : 0.0f);
+      mask = d < c.comm_radius;
+    } else if (s < n + t.gs) {
+      const int gi = t.spread ? (s - n) : i;
+      const float* fg = s_fg + gi * 4;
+      f = make_float4(__fsub_rn(fi[0], fg[0]), __fsub_rn(fi[1], fg[1]), __fsub_rn(fi[2], fg[2]), __fsub_rn(fi[3], fg[3]));
+      mask = true;
+    } else {
+      const int m = s - n - t.gs;
+      if (t.lidar) {
+        const float* hp = s_ob + (i * t.per + m) * SD;
+        const float lx = __fsub_rn(px, hp[0]), ly = __fsub_rn(py, hp[1]);
+        f = make_float4(lx, ly, 0.0f, 0.0f);
+        mask = dist_rn(lx, ly) < c.lidar_mask_radius;
+      } else {
+        const float* xo = s_ob + m * SD;
+        const float* xi = s_ag + i * SD;
+        f = make_float4(__fsub_rn(xi[0], xo[0]), __fsub_rn(xi[1], xo[1]), __fsub_rn(xi[2], xo[2]), __fsub_rn(xi[3], xo[3]));
+        mask = dist_rn(__fsub_rn(xi[0], xo[0]), __fsub_rn(xi[1], xo[1])) < c.comm_radius;
+      }
+    }
+    reinterpret_cast<float4*>(a.efeat)[(size_t)g * n * S + idx] = f;
+    a.emask[(size_t)g * n * S + idx] = mask ? 1.0f : 0.0f;
+  }
+}
+
+extern "C" int32_t dgppo_graph_feats(const dgppo_env_cfg* cfg, const float* agent, int64_t agent_se, int64_t agent_st,
+                                     const float* goal, const float* obst, const float* hits, int64_t hits_se,
+                                     int64_t hits_st, const int32_t* env_ids, int32_t n_env, int32_t n_time, float* Xa,
+                                     float* Xo, float* efeat, float* emask, int32_t Fp, void* stream) {
+  int32_t rc = dgppo_validate_cfg(cfg);
+  if (rc) return rc;
+  DGPPO_REQUIRE(n_env >= 0 && n_time >= 0, "graph_feats: negative counts");
+  if (n_env == 0 || n_time == 0) return 0;
+  DGPPO_REQUIRE(agent && goal && Xa && efeat && emask, "graph_feats: NULL operand");
+  DGPPO_REQUIRE(Fp >= cfg->node_dim && Fp <= 32, "graph_feats: Fp must be in [node_dim, 32]");
+  FeatArgs a;
+  a.cfg = *cfg; a.t = make_topo(*cfg);
+  const int n_on = a.t.Ns - a.t.n - a.t.ng;
+  DGPPO_REQUIRE(n_on == 0 || Xo, "graph_feats: Xo is NULL");
+  DGPPO_REQUIRE(a.t.Ns == a.t.n || Xo, "graph_feats: Xo is NULL");
+  if (n_on > 0) {
+    if (a.t.lidar) DGPPO_REQUIRE(hits, "graph_feats: hits is NULL");
+    else DGPPO_REQUIRE(obst, "graph_feats: obst is NULL");
+  }
+  DGPPO_REQUIRE(((uintptr_t)efeat & 15) == 0, "graph_feats: efeat must be 16-byte aligned");
+  a.agent = agent; a.agent_se = agent_se; a.agent_st = agent_st; a.goal = goal; a.obst = obst;
+  a.hits = hits; a.hits_se = hits_se; a.hits_st = hits_st; a.env_ids = env_ids; a.n_env = n_env; a.n_time = n_time;
+  a.Xa = Xa; a.Xo = Xo; a.efeat = efeat; a.emask = emask; a.Fp = Fp;
+  const int SD = cfg->state_dim;
+  const size_t smem = sizeof(float) * ((size_t)a.t.n * SD + a.t.ng * SD + (size_t)n_on * SD + a.t.n * 4 + a.t.ng * 4);
+  const long G = (long)n_env * n_time;
+  if (SD == 5) hipLaunchKernelGGL(graph_feats_kernel<5>, dim3(G), dim3(128), smem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(graph_feats_kernel<4>, dim3(G), dim3(128), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention forward: one workgroup per graph
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnArgs {
+  Topo t;
+  int F, H, Kp;          // feature width of this layer's inputs, heads, padded width of zcat
+  const float* qt;       // [G*n, H*F]
+  const float* Xa;       // [G*n, F]
+  const float* Xo;       // [G*(Ns-n), F]
+  const float* efeat;    // [G*n, S, 4]
+  const float* emask;    // [G*n, S]
+  float* zcat;           // [G*n, Kp]   = [x_i | per head: sum a x_s (F), sum a e (4) | 1 | 0-pad]
+  float* attn;           // [G*n, S, H]
+  // backward
+  const float* dzcat;    // [G*n, Kp]
+  float* dqt;            // [G*n, H*F]
+  float* dXa;            // [G*n, F]   (written, not accumulated) or NULL
+  float* dXo;            // [G*(Ns-n), F] or NULL
+  int G;
+};
+
+__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ float sm[];
+  const Topo& t = a.t;
+  const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int n = t.n, S = t.S, Ns = t.Ns, F = a.F, H = a.H, Fl = F + 1;
+  float* s_x = sm;                      // Ns * Fl
+  float* s_q = s_x + Ns * Fl;           // n * H * Fl
+  float* s_e = s_q + n * H * Fl;        // n * S * 4
+  float* s_m = s_e + n * S * 4;         // n * S
+  float* s_a = s_m + n * S;             // n * S * H
+  for (int idx = tid; idx < Ns * F; idx += nt) {
+    const int nd = idx / F, f = idx - nd * F;
+    s_x[nd * Fl + f] = (nd < n) ? a.Xa[((size_t)g * n + nd) * F + f] : a.Xo[((size_t)g * (Ns - n) + (nd - n)) * F + f];
+  }
+  for (int idx = tid; idx < n * H * F; idx += nt) {
+    const int ih = idx / F, f = idx - ih * F;
+    s_q[ih * Fl + f] = a.qt[(size_t)g * n * H * F + idx];
+  }
+  for (int idx = tid; idx < n * S * 4; idx += nt) s_e[idx] = a.efeat[(size_t)g * n * S * 4 + idx];
+  for (int idx = tid; idx < n * S; idx += nt) s_m[idx] = a.emask[(size_t)g * n * S + idx];
+  __syncthreads();
+  // logits
+  for (int idx = tid; idx < n * S * H; idx += nt) {
+    const int h = idx % H, is = idx / H;
+    const int i = is / S, s = is - i * S;
+    const float* x = s_x + sender_node(t, i, s) * Fl;
+    const float* q = s_q + (i * H + h) * Fl;
+    float acc = 0.0f;
+    for (int f = 0; f < F; ++f) acc = fmaf(q[f], x[f], acc);
+    s_a[idx] = acc;
+  }
+  __syncthreads();
+  // masked softmax over the slots of (i, h)   [jraph.segment_softmax: subtract max, exp, normalise]
+  for (int ih = tid; ih < n * H; ih += nt) {
+    const int i = ih / H, h = ih - i * H;
+    float mx = -INFINITY;
+    for (int s = 0; s < S; ++s)
+      if (s_m[i * S + s] != 0.0f) mx = fmaxf(mx, s_a[(i * S + s) * H + h]);
+    float den = 0.0f;
+    for (int s = 0; s < S; ++s) {
+      float ev = 0.0f;
+      if (s_m[i * S + s] != 0.0f) ev = expf(s_a[(i * S + s) * H + h] - mx);
+      s_a[(i * S + s) * H + h] = ev;
+      den += ev;
+    }
+    const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
+    for (int s = 0; s < S; ++s) s_a[(i * S + s) * H + h] *= inv;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n * S * H; idx += nt) a.attn[(size_t)g * n * S * H + idx] = s_a[idx];
+  // aggregation of raw sender / edge features
+  const int W = F + 4;
+  for (int idx = tid; idx < n * H * W; idx += nt) {
+    const int w = idx % W, ih = idx / W;
+    const int i = ih / H, h = ih - i * H;
+    float acc = 0.0f;
+    if (w < F) {
+      for (int s = 0; s < S; ++s) {
+        const float av = s_a[(i * S + s) * H + h];
+        if (av != 0.0f) acc = fmaf(av, s_x[sender_node(t, i, s) * Fl + w], acc);
+      }
+    } else {
+      // masked slots carry a == 0; their (unclamped, up to 5e5) edge features must not produce 0*inf/NaN: skip them
+      for (int s = 0; s < S; ++s) {
+        const float av = s_a[(i * S + s) * H + h];
+        if (av != 0.0f) acc = fmaf(av, s_e[(i * S + s) * 4 + (w - F)], acc);
+      }
+    }
+    a.zcat[((size_t)g * n + i) * a.Kp + F + h * W + w] = acc;
+  }
+  for (int idx = tid; idx < n * F; idx += nt) {
+    const int i = idx / F, f = idx - i * F;
+    a.zcat[((size_t)g * n + i) * a.Kp + f] = s_x[i * Fl + f];
+  }
+  const int kc = F + H * W;  // index of the constant-one column (carries mean_h b_v)
+  for (int idx = tid; idx < n * (a.Kp - kc); idx += nt) {
+    const int i = idx / (a.Kp - kc), c = kc + idx - i * (a.Kp - kc);
+    a.zcat[((size_t)g * n + i) * a.Kp + c] = (c == kc) ? 1.0f : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
+  extern __shared__ float sm[];
+  const Topo& t = a.t;
+  const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int n = t.n, S = t.S, Ns = t.Ns, F = a.F, H = a.H, Fl = F + 1, W = F + 4;
+  float* s_x = sm;                      // Ns * Fl
+  float* s_q = s_x + Ns * Fl;           // n * H * Fl
+  float* s_e = s_q + n * H * Fl;        // n * S * 4
+  float* s_a = s_e + n * S * 4;         // n * S * H   attention weights
+  float* s_d = s_a + n * S * H;         // n * S * H   dA then dlogit
+  float* s_z = s_d + n * S * H;         // n * H * (W+1)  dz (aggregated part)
+  const int Wl = W + 1;
+  for (int idx = tid; idx < Ns * F; idx += nt) {
+    const int nd = idx / F, f = idx - nd * F;
+    s_x[nd * Fl + f] = (nd < n) ? a.Xa[((size_t)g * n + nd) * F + f] : a.Xo[((size_t)g * (Ns - n) + (nd - n)) * F + f];
+  }
+  for (int idx = tid; idx < n * H * F; idx += nt) {
+    const int ih = idx / F, f = idx - ih * F;
+    s_q[ih * Fl + f] = a.qt[(size_t)g * n * H * F + idx];
+  }
+  for (int idx = tid; idx < n * S * 4; idx += nt) s_e[idx] = a.efeat[(size_t)g * n * S * 4 + idx];
+  for (int idx = tid; idx < n * S * H; idx += nt) s_a[idx] = a.attn[(size_t)g * n * S * H + idx];
+  for (int idx = tid; idx < n * H * W; idx += nt) {
+    const int w = idx % W, ih = idx / W;
+    const int i = ih / H, h = ih - i * H;
+    s_z[ih * Wl + w] = a.dzcat[((size_t)g * n + i) * a.Kp + F + h * W + w];
+  }
+  __syncthreads();
+  // dA[i,s,h] = dzx[i,h,:] . x_s + dze[i,h,:] . e_is
+  for (int idx = tid; idx < n * S * H; idx += nt) {
+    const int h = idx % H, is = idx / H;
+    const int i = is / S, s = is - i * S;
+    float acc = 0.0f;
+    if (s_a[idx] != 0.0f) {
+      const float* x = s_x + sender_node(t, i, s) * Fl;
+      const float* dz = s_z + (i * H + h) * Wl;
+      for (int f = 0; f < F; ++f) acc = fmaf(dz[f], x[f], acc);
+      for (int c = 0; c < 4; ++c) acc = fmaf(dz[F + c], s_e[is * 4 + c], acc);
+    }
+    s_d[idx] = acc;
+  }
+  __syncthreads();
+  // softmax backward: dlogit = a * (dA - sum_s a dA)
+  for (int ih = tid; ih < n * H; ih += nt) {
+    const int i = ih / H, h = ih - i * H;
+    float dot = 0.0f;
+    for (int s = 0; s < S; ++s) dot = fmaf(s_a[(i * S + s) * H + h], s_d[(i * S + s) * H + h], dot);
+    for (int s = 0; s < S; ++s) {
+      const int k = (i * S + s) * H + h;
+      s_d[k] = s_a[k] * (s_d[k] - dot);
+    }
+  }
+  __syncthreads();
+  // dqt[i,h,f] = sum_s dlogit[i,s,h] x_s[f]
+  for (int idx = tid; idx < n * H * F; idx += nt) {
+    const int f = idx % F, ih = idx / F;
+    const int i = ih / H, h = ih - i * H;
+    float acc = 0.0f;
+    for (int s = 0; s < S; ++s) {
+      const float dv = s_d[(i * S + s) * H + h];
+      if (dv != 0.0f) acc = fmaf(dv, s_x[sender_node(t, i, s) * Fl + f], acc);
+    }
+    a.dqt[(size_t)g * n * H * F + idx] = acc;
+  }
+  // d x_nd[f] = sum over receivers i of sum_h (a * dzx + dlogit * qt)  (+ the direct x_i part for agents)
+  if (a.dXa != nullptr) {
+    for (int idx = tid; idx < Ns * F; idx += nt) {
+      const int nd = idx / F, f = idx - nd * F;
+      if (nd >= n && a.dXo == nullptr) continue;
+      float acc = 0.0f;
+      for (int i = 0; i < n; ++i) {
+        const int s = slot_of(t, nd, i);
+        if (s < 0) continue;
+        for (int h = 0; h < H; ++h) {
+          const int k = (i * S + s) * H + h;
+          acc = fmaf(s_a[k], s_z[(i * H + h) * Wl + f], acc);
+          acc = fmaf(s_d[k], s_q[(i * H + h) * Fl + f], acc);
+        }
+      }
+      if (nd < n) a.dXa[((size_t)g * n + nd) * F + f] = acc + a.dzcat[((size_t)g * n + nd) * a.Kp + f];
+      else a.dXo[((size_t)g * (Ns - n) + (nd - n)) * F + f] = acc;
+    }
+  }
+}
+
+static int32_t attn_check(const dgppo_env_cfg* cfg, int F, int H, int Kp, int G, AttnArgs& a) {
+  int32_t rc = dgppo_validate_cfg(cfg);
+  if (rc) return rc;
+  a.t = make_topo(*cfg);
+  DGPPO_REQUIRE(F >= 1 && F <= 64 && H >= 1 && H <= 8, "attn: bad F=%d H=%d", F, H);
+  DGPPO_REQUIRE(Kp >= F + H * (F + 4) + 1, "attn: Kp=%d too small", Kp);
+  DGPPO_REQUIRE(G >= 0, "attn: G < 0");
+  a.F = F; a.H = H; a.Kp = Kp; a.G = G;
+  return 0;
+}
+
+extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* qt,
+                                  const float* Xa, const float* Xo, const float* efeat, const float* emask, float* zcat,
+                                  float* attn, int32_t G, void* stream) {
+  AttnArgs a{};
+  int32_t rc = attn_check(cfg, F, H, Kp, G, a);
+  if (rc) return rc;
+  if (G == 0) return 0;
+  DGPPO_REQUIRE(qt && Xa && efeat && emask && zcat && attn, "attn_fwd: NULL operand");
+  DGPPO_REQUIRE(a.t.Ns == a.t.n || Xo, "attn_fwd: Xo is NULL");
+  a.qt = qt; a.Xa = Xa; a.Xo = Xo; a.efeat = efeat; a.emask = emask; a.zcat = zcat; a.attn = attn;
+  const Topo& t = a.t;
+  const size_t smem = sizeof(float) * ((size_t)t.Ns * (F + 1) + (size_t)t.n * H * (F + 1) + (size_t)t.n * t.S * 5 +
+                                       (size_t)t.n * t.S * H);
+  DGPPO_REQUIRE(smem <= 64 * 1024, "attn_fwd: graph too large for LDS (%zu B)", smem);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
+                                  const float* attn, const float* qt, const float* Xa, const float* Xo,
+                                  const float* efeat, float* dqt, float* dXa, float* dXo, int32_t G, void* stream) {
+  AttnArgs a{};
+  int32_t rc = attn_check(cfg, F, H, Kp, G, a);
+  if (rc) return rc;
+  if (G == 0) return 0;
+  DGPPO_REQUIRE(dzcat && attn && qt && Xa && efeat && dqt, "attn_bwd: NULL operand");
+  DGPPO_REQUIRE(a.t.Ns == a.t.n || Xo, "attn_bwd: Xo is NULL");
+  DGPPO_REQUIRE(!(dXo && !dXa), "attn_bwd: dXo needs dXa");
+  a.dzcat = dzcat; a.attn = (float*)attn; a.qt = qt; a.Xa = Xa; a.Xo = Xo; a.efeat = efeat; a.dqt = dqt; a.dXa = dXa; a.dXo = dXo;
+  const Topo& t = a.t;
+  const size_t smem = sizeof(float) * ((size_t)t.Ns * (F + 1) + (size_t)t.n * H * (F + 1) + (size_t)t.n * t.S * 4 +
+                                       2 * (size_t)t.n * t.S * H + (size_t)t.n * H * (F + 5));
+  DGPPO_REQUIRE(smem <= 64 * 1024, "attn_bwd: graph too large for LDS (%zu B)", smem);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}

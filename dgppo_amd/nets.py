@@ -1,0 +1,368 @@
+"""Host-side composition of the HIP building blocks into the reference's three networks
+(PolicyNet+TanhNormal: dgppo/algo/module/policy.py:20-78; RStateFn / DecRStateFn: dgppo/algo/module/value.py:15-79).
+
+Parameters live in ONE flat fp32 device buffer per network (so grad-norm / clip / Adam / all-reduce are single
+kernels); `layout` maps flax-style names to (offset, shape).  Torch tensors are storage only."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import ops_nn as K
+
+H_HEADS = 3
+MSG_DIM = 32
+OUT_DIM = 64
+HID = 64
+
+
+def _ceil4(x):
+    return (x + 3) // 4 * 4
+
+
+class Layout:
+    def __init__(self):
+        self.entries: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.size = 0
+
+    def add(self, name, *shape):
+        n = int(np.prod(shape))
+        # keep every segment 16-byte aligned (float4 loads, MFMA-friendly)
+        self.size = (self.size + 3) // 4 * 4
+        self.entries[name] = (self.size, tuple(shape))
+        self.size += n
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        off, shape = self.entries[name]
+        return flat[off:off + int(np.prod(shape))].view(*shape)
+
+
+def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int) -> Layout:
+    """kind: 'policy' | 'Vl' | 'Vh'.  Dense kernels are [in, out] like flax."""
+    L = Layout()
+    f = node_dim
+    for l in range(gnn_layers):
+        d = OUT_DIM if l == gnn_layers - 1 else MSG_DIM
+        hd = H_HEADS * d
+        for nm, shp in (("Wq", (f, hd)), ("bq", (hd,)), ("Wk", (f, hd)), ("bk", (hd,)), ("Wv", (f, hd)), ("bv", (hd,)),
+                        ("We", (4, hd)), ("Wu", (f, d)), ("bu", (d,))):
+            L.add(f"gnn{l}.{nm}", *shp)
+        f = d
+    for i in (1, 2):
+        L.add(f"mlp.W{i}", HID, HID)
+        L.add(f"mlp.b{i}", HID)
+        L.add(f"mlp.g{i}", HID)
+        L.add(f"mlp.be{i}", HID)
+    L.add("gru.Wi", HID, 3 * HID)   # ir | iz | in
+    L.add("gru.bi", 3 * HID)
+    L.add("gru.Wh", HID, 3 * HID)   # hr | hz | hn
+    L.add("gru.bhn", HID)
+    if kind == "policy":
+        L.add("head.Ws", HID, HID)      # ScaleHid
+        L.add("head.bs", HID)
+        L.add("head.Wms", HID, 2 * n_out)  # OutputDenseMean | OutputDenseStdTrans
+        L.add("head.bms", 2 * n_out)
+    else:
+        L.add("head.Wo", HID, n_out)
+        L.add("head.bo", n_out)
+    return L
+
+
+class Arena:
+    """named scratch tensors, reused across calls (sized for the largest request seen)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str, *shape, dtype=torch.float32, zero=False) -> torch.Tensor:
+        n = int(np.prod(shape))
+        b = self.bufs.get(name)
+        if b is None or b.numel() < n or b.dtype != dtype:
+            b = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self.bufs[name] = b
+        v = b[:n].view(*shape)
+        if zero:
+            v.zero_()
+        return v
+
+
+class GraphFeats:
+    """dense per-graph features shared by the three networks (output of dgppo_graph_feats)."""
+
+    def __init__(self, cfg: N.EnvCfg, G: int, arena: Arena, tag: str):
+        self.cfg, self.G = cfg, G
+        n, S = cfg.n_agents, cfg.fan_in
+        self.n_other = cfg.num_nodes - 1 - n
+        self.Fp = 8
+        self.Xa = arena.get(f"{tag}.Xa0", G * n, self.Fp)
+        self.Xo = arena.get(f"{tag}.Xo0", max(G * self.n_other, 1), self.Fp)[:G * self.n_other]
+        self.efeat = arena.get(f"{tag}.efeat", G * n, S, 4)
+        self.emask = arena.get(f"{tag}.emask", G * n, S)
+
+    def compute(self, agent, agent_se, agent_st, goal, obst, hits, hits_se, hits_st, env_ids, n_env, n_time):
+        assert n_env * n_time == self.G
+        K.graph_feats(self.cfg, agent, agent_se, agent_st, goal, obst, hits, hits_se, hits_st, env_ids, n_env, n_time,
+                      self.Xa, self.Xo if self.n_other > 0 else None, self.efeat, self.emask, self.Fp)
+        return self
+
+
+class Net:
+    """One network = flat params + flat grads + prepared GNN weights + forward/backward over a batch of graphs."""
+
+    def __init__(self, kind: str, cfg: N.EnvCfg, gnn_layers: int, n_out: int, device):
+        assert kind in ("policy", "Vl", "Vh")
+        self.kind, self.cfg, self.gnn_layers, self.n_out, self.device = kind, cfg, gnn_layers, n_out, device
+        self.layout = make_layout(kind, cfg.node_dim, gnn_layers, n_out)
+        self.params = torch.zeros(self.layout.size, device=device)
+        self.grads = torch.zeros(self.layout.size, device=device)
+        self.arena = Arena(device)
+        # per-layer dims: F (true input width), Fp (padded), D, Kp
+        self.dims = []
+        f = cfg.node_dim
+        for l in range(gnn_layers):
+            d = OUT_DIM if l == gnn_layers - 1 else MSG_DIM
+            fp = 8 if l == 0 else f
+            kp = _ceil4(fp + H_HEADS * (fp + 4) + 1)
+            self.dims.append((f, fp, d, kp))
+            f = d
+        # prepared weights (+ their grads) in one flat buffer each
+        self.prep_layout = Layout()
+        for l, (f, fp, d, kp) in enumerate(self.dims):
+            self.prep_layout.add(f"gnn{l}.Mcat", fp, H_HEADS * fp)
+            self.prep_layout.add(f"gnn{l}.cvec", H_HEADS * fp)
+            self.prep_layout.add(f"gnn{l}.Wout", kp, d)
+        self.prep = torch.zeros(self.prep_layout.size, device=device)
+        self.prep_grads = torch.zeros(self.prep_layout.size, device=device)
+
+    # ---- parameter access ------------------------------------------------------------------------------------------
+    def p(self, name):
+        return self.layout.view(self.params, name)
+
+    def g(self, name):
+        return self.layout.view(self.grads, name)
+
+    def pp(self, name):
+        return self.prep_layout.view(self.prep, name)
+
+    def pg(self, name):
+        return self.prep_layout.view(self.prep_grads, name)
+
+    def prepare(self):
+        """params -> prepared GNN weights (call after every parameter change)."""
+        for l, (f, fp, d, kp) in enumerate(self.dims):
+            q = lambda nm: self.p(f"gnn{l}.{nm}")
+            K.gnn_prep(q("Wq"), q("bq"), q("Wk"), q("Wv"), q("bv"), q("We"), q("Wu"), self.pp(f"gnn{l}.Mcat"),
+                       self.pp(f"gnn{l}.cvec"), self.pp(f"gnn{l}.Wout"), f, fp, d, H_HEADS, kp)
+
+    def zero_grads(self):
+        self.grads.zero_()
+        self.prep_grads.zero_()
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def forward(self, feats: GraphFeats, n_seq: int, T: int, h0: Optional[torch.Tensor], tag: str = "f"):
+        """Trunk + GRU + output Dense(s).  Graphs are ordered (group, time): G = (n_seq / n_inner) * T.
+        Returns a dict of activations (views into this net's arena, valid until the next forward with the same tag)."""
+        cfg, G, A = self.cfg, feats.G, self.arena
+        n = cfg.n_agents
+        R = G * n
+        Ro = G * feats.n_other
+        act = {"feats": feats, "G": G, "n_seq": n_seq, "T": T}
+        Xa, Xo = feats.Xa, feats.Xo
+        for l, (f, fp, d, kp) in enumerate(self.dims):
+            qt = A.get(f"{tag}.qt{l}", R, H_HEADS * fp)
+            K.dense_fwd(Xa, self.pp(f"gnn{l}.Mcat"), self.pp(f"gnn{l}.cvec"), qt)
+            zcat = A.get(f"{tag}.zcat{l}", R, kp)
+            attn = A.get(f"{tag}.attn{l}", R, cfg.fan_in, H_HEADS)
+            K.attn_fwd(cfg, fp, H_HEADS, kp, qt, Xa, Xo if Ro > 0 else None, feats.efeat, feats.emask, zcat, attn, G)
+            Xa_n = A.get(f"{tag}.Xa{l + 1}", R, d)
+            K.dense_fwd(zcat, self.pp(f"gnn{l}.Wout"), self.p(f"gnn{l}.bu"), Xa_n, act=1)
+            act[f"Xa{l}"], act[f"Xo{l}"], act[f"qt{l}"], act[f"zcat{l}"], act[f"attn{l}"] = Xa, Xo, qt, zcat, attn
+            if l < self.gnn_layers - 1 and Ro > 0:
+                Xo_n = A.get(f"{tag}.Xo{l + 1}", Ro, d)
+                # goals / hits / obstacles receive no messages: relu(W_u x + b_u)  (gnn.py:109-111 with aggr = 0)
+                K.dense_fwd(Xo, self.pp(f"gnn{l}.Wout")[:fp], self.p(f"gnn{l}.bu"), Xo_n, act=1)
+                Xo = Xo_n
+            Xa = Xa_n
+        act[f"Xa{self.gnn_layers}"] = Xa
+        if self.kind == "Vl":  # RStateFn: mean over agents (value.py:33)
+            pooled = A.get(f"{tag}.pool", G, OUT_DIM)
+            K.mean_agents(Xa, pooled, G, n, OUT_DIM)
+            x, Rh, n_inner = pooled, G, 1
+        else:
+            x, Rh, n_inner = Xa, R, n
+        act["Rh"], act["n_inner"], act["mlp_in"] = Rh, n_inner, x
+        for i in (1, 2):
+            pre = A.get(f"{tag}.p{i}", Rh, HID)
+            K.dense_fwd(x, self.p(f"mlp.W{i}"), self.p(f"mlp.b{i}"), pre)
+            y = A.get(f"{tag}.y{i}", Rh, HID)
+            st = A.get(f"{tag}.st{i}", Rh, 2)
+            K.ln_relu_fwd(pre, self.p(f"mlp.g{i}"), self.p(f"mlp.be{i}"), y, st)
+            act[f"p{i}"], act[f"y{i}"], act[f"st{i}"] = pre, y, st
+            x = y
+        gi = A.get(f"{tag}.gi", Rh, 3 * HID)
+        K.dense_fwd(x, self.p("gru.Wi"), self.p("gru.bi"), gi)
+        hs = A.get(f"{tag}.hs", Rh, HID)
+        hprev = A.get(f"{tag}.hprev", Rh, HID)
+        gates = A.get(f"{tag}.gates", Rh, 4 * HID)
+        assert n_seq * T == Rh, (n_seq, T, Rh)
+        K.gru_fwd(gi, self.p("gru.Wh"), self.p("gru.bhn"), h0, hs, hprev, gates, n_seq, T, n_inner)
+        act["gi"], act["hs"], act["hprev"], act["gates"] = gi, hs, hprev, gates
+        if self.kind == "policy":
+            u = A.get(f"{tag}.u", Rh, HID)
+            K.dense_fwd(hs, self.p("head.Ws"), self.p("head.bs"), u)
+            ms = A.get(f"{tag}.ms", Rh, 4)
+            K.dense_fwd(u, self.p("head.Wms"), self.p("head.bms"), ms)
+            act["u"], act["ms"] = u, ms
+        else:
+            v = A.get(f"{tag}.v", Rh, self.n_out)
+            K.dense_fwd(hs, self.p("head.Wo"), self.p("head.bo"), v)
+            act["v"] = v
+        return act
+
+    # ---- backward --------------------------------------------------------------------------------------------------
+    def backward(self, act, dout: torch.Tensor, tag: str = "b"):
+        """dout = d loss / d ms [Rh,4] (policy) or d loss / d v [Rh,n_out] (values).  Accumulates into self.grads."""
+        cfg, A = self.cfg, self.arena
+        G, Rh, n_inner, n_seq, T = act["G"], act["Rh"], act["n_inner"], act["n_seq"], act["T"]
+        n = cfg.n_agents
+        R = G * n
+        feats: GraphFeats = act["feats"]
+        Ro = G * feats.n_other
+        hs = act["hs"]
+        dhs = A.get(f"{tag}.dhs", Rh, HID)
+        if self.kind == "policy":
+            K.dense_bwd_w(act["u"], dout, self.g("head.Wms"), self.g("head.bms"))
+            du = A.get(f"{tag}.du", Rh, HID)
+            K.dense_fwd(dout, self.p("head.Wms"), None, du, trans_w=True)
+            K.dense_bwd_w(hs, du, self.g("head.Ws"), self.g("head.bs"))
+            K.dense_fwd(du, self.p("head.Ws"), None, dhs, trans_w=True)
+        else:
+            K.dense_bwd_w(hs, dout, self.g("head.Wo"), self.g("head.bo"))
+            K.dense_fwd(dout, self.p("head.Wo"), None, dhs, trans_w=True)
+        dgi = A.get(f"{tag}.dgi", Rh, 3 * HID)
+        dgh = A.get(f"{tag}.dgh", Rh, 3 * HID)
+        K.gru_bwd(dhs, self.p("gru.Wh"), act["hprev"], act["gates"], dgi, dgh, n_seq, T, n_inner)
+        # hr / hz have no bias (flax GRUCell); only the hn column block carries one
+        K.dense_bwd_w(act["hprev"], dgh[:, :2 * HID], self.g("gru.Wh")[:, :2 * HID], None)
+        K.dense_bwd_w(act["hprev"], dgh[:, 2 * HID:], self.g("gru.Wh")[:, 2 * HID:], self.g("gru.bhn"))
+        K.dense_bwd_w(act["y2"], dgi, self.g("gru.Wi"), self.g("gru.bi"))
+        dy = A.get(f"{tag}.dy", Rh, HID)
+        K.dense_fwd(dgi, self.p("gru.Wi"), None, dy, trans_w=True)
+        x_in = {1: act["mlp_in"], 2: act["y1"]}
+        for i in (2, 1):
+            dpre = A.get(f"{tag}.dpre{i}", Rh, HID)
+            K.ln_relu_bwd(act[f"p{i}"], act[f"y{i}"], act[f"st{i}"], self.p(f"mlp.g{i}"), dy, dpre, self.g(f"mlp.g{i}"),
+                          self.g(f"mlp.be{i}"))
+            K.dense_bwd_w(x_in[i], dpre, self.g(f"mlp.W{i}"), self.g(f"mlp.b{i}"))
+            dy = A.get(f"{tag}.dyy{i}", Rh, HID)
+            K.dense_fwd(dpre, self.p(f"mlp.W{i}"), None, dy, trans_w=True)
+        if self.kind == "Vl":
+            dXa = A.get(f"{tag}.dXaL", R, OUT_DIM)
+            K.mean_agents(dy, dXa, G, n, OUT_DIM, backward=True)
+        else:
+            dXa = dy
+        dXo = None
+        for l in range(self.gnn_layers - 1, -1, -1):
+            f, fp, d, kp = self.dims[l]
+            Xa_n = act[f"Xa{l + 1}"]
+            K.relu_bwd(dXa, Xa_n)
+            K.dense_bwd_w(act[f"zcat{l}"], dXa, self.pg(f"gnn{l}.Wout"), self.g(f"gnn{l}.bu"))
+            dz = A.get(f"{tag}.dz{l}", R, kp)
+            K.dense_fwd(dXa, self.pp(f"gnn{l}.Wout"), None, dz, trans_w=True)
+            if dXo is not None:  # other nodes of layer l+1: relu(W_u x + b_u)
+                Xo_n = act[f"Xo{l + 1}"]
+                K.relu_bwd(dXo, Xo_n)
+                K.dense_bwd_w(act[f"Xo{l}"], dXo, self.pg(f"gnn{l}.Wout")[:fp], self.g(f"gnn{l}.bu"))
+            dqt = A.get(f"{tag}.dqt{l}", R, H_HEADS * fp)
+            need_dx = l > 0
+            dXa_l = A.get(f"{tag}.dXa{l}", R, fp) if need_dx else None
+            dXo_prev = dXo
+            dXo_l = A.get(f"{tag}.dXo{l}", Ro, fp) if (need_dx and Ro > 0) else None
+            K.attn_bwd(cfg, fp, H_HEADS, kp, dz, act[f"attn{l}"], act[f"qt{l}"], act[f"Xa{l}"],
+                       act[f"Xo{l}"] if Ro > 0 else None, feats.efeat, dqt, dXa_l, dXo_l, G)
+            K.dense_bwd_w(act[f"Xa{l}"], dqt, self.pg(f"gnn{l}.Mcat"), self.pg(f"gnn{l}.cvec"))
+            if need_dx:
+                K.dense_fwd(dqt, self.pp(f"gnn{l}.Mcat"), None, dXa_l, accumulate=True, trans_w=True)
+                if dXo_prev is not None and dXo_l is not None:
+                    K.dense_fwd(dXo_prev, self.pp(f"gnn{l}.Wout")[:fp], None, dXo_l, accumulate=True, trans_w=True)
+            dXa, dXo = dXa_l, dXo_l
+        for l, (f, fp, d, kp) in enumerate(self.dims):
+            q = lambda nm: self.p(f"gnn{l}.{nm}")
+            gq = lambda nm: self.g(f"gnn{l}.{nm}")
+            K.gnn_unprep(self.pg(f"gnn{l}.Mcat"), self.pg(f"gnn{l}.cvec"), self.pg(f"gnn{l}.Wout"), q("Wq"), q("bq"), q("Wk"),
+                         gq("Wq"), gq("bq"), gq("Wk"), gq("Wv"), gq("bv"), gq("We"), gq("Wu"), f, fp, d, H_HEADS, kp)
+        self.prep_grads.zero_()
+
+    # ---- flax-tree interop ----------------------------------------------------------------------------
+    def load_tree(self, tree: dict):
+        """tree = {'params': {...}} with the flax names of SURVEY A.9 (numpy or torch leaves)."""
+        t = tree["params"]
+        to = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.device)
+        if self.kind == "policy":
+            base, gnn, head_name = t["PolicyNet_0"], t["PolicyNet_0"]["GraphTransformerGNN_0"], "PolicyGNNHead"
+        else:
+            base, gnn, head_name = t, t["GraphTransformerGNN_0"], "ValueGNNHead"
+        for l in range(self.gnn_layers):
+            gl = gnn[f"GraphTransformer_{l}"]
+            for nm, dn, key in (("Wq", "Dense_0", "kernel"), ("bq", "Dense_0", "bias"), ("Wk", "Dense_1", "kernel"),
+                                ("bk", "Dense_1", "bias"), ("Wv", "Dense_2", "kernel"), ("bv", "Dense_2", "bias"),
+                                ("We", "Dense_3", "kernel"), ("Wu", "Dense_4", "kernel"), ("bu", "Dense_4", "bias")):
+                self.p(f"gnn{l}.{nm}").copy_(to(gl[dn][key]))
+        hd = base[head_name]
+        for i in (1, 2):
+            self.p(f"mlp.W{i}").copy_(to(hd[f"Dense_{i - 1}"]["kernel"]))
+            self.p(f"mlp.b{i}").copy_(to(hd[f"Dense_{i - 1}"]["bias"]))
+            self.p(f"mlp.g{i}").copy_(to(hd[f"LayerNorm_{i - 1}"]["scale"]))
+            self.p(f"mlp.be{i}").copy_(to(hd[f"LayerNorm_{i - 1}"]["bias"]))
+        gr = base["RNN_0"]["GRUCell_1"]
+        self.p("gru.Wi").copy_(torch.cat([to(gr[k]["kernel"]) for k in ("ir", "iz", "in")], dim=1))
+        self.p("gru.bi").copy_(torch.cat([to(gr[k]["bias"]) for k in ("ir", "iz", "in")]))
+        self.p("gru.Wh").copy_(torch.cat([to(gr[k]["kernel"]) for k in ("hr", "hz", "hn")], dim=1))
+        self.p("gru.bhn").copy_(to(gr["hn"]["bias"]))
+        if self.kind == "policy":
+            self.p("head.Ws").copy_(to(t["ScaleHid"]["kernel"]))
+            self.p("head.bs").copy_(to(t["ScaleHid"]["bias"]))
+            self.p("head.Wms").copy_(torch.cat([to(t["OutputDenseMean"]["kernel"]), to(t["OutputDenseStdTrans"]["kernel"])], 1))
+            self.p("head.bms").copy_(torch.cat([to(t["OutputDenseMean"]["bias"]), to(t["OutputDenseStdTrans"]["bias"])]))
+        else:
+            self.p("head.Wo").copy_(to(t["Dense_0"]["kernel"]))
+            self.p("head.bo").copy_(to(t["Dense_0"]["bias"]))
+        self.prepare()
+
+    def to_tree(self, flat: Optional[torch.Tensor] = None) -> dict:
+        """flat buffer (params by default, or grads) -> nested dict of numpy arrays with the flax names."""
+        flat = self.params if flat is None else flat
+        v = lambda nm: self.layout.view(flat, nm).detach().cpu().numpy().copy()
+        gnn = {}
+        for l in range(self.gnn_layers):
+            gnn[f"GraphTransformer_{l}"] = {
+                "Dense_0": {"kernel": v(f"gnn{l}.Wq"), "bias": v(f"gnn{l}.bq")},
+                "Dense_1": {"kernel": v(f"gnn{l}.Wk"), "bias": v(f"gnn{l}.bk")},
+                "Dense_2": {"kernel": v(f"gnn{l}.Wv"), "bias": v(f"gnn{l}.bv")},
+                "Dense_3": {"kernel": v(f"gnn{l}.We")},
+                "Dense_4": {"kernel": v(f"gnn{l}.Wu"), "bias": v(f"gnn{l}.bu")},
+            }
+        head = {}
+        for i in (1, 2):
+            head[f"Dense_{i - 1}"] = {"kernel": v(f"mlp.W{i}"), "bias": v(f"mlp.b{i}")}
+            head[f"LayerNorm_{i - 1}"] = {"scale": v(f"mlp.g{i}"), "bias": v(f"mlp.be{i}")}
+        Wi, bi, Wh = v("gru.Wi"), v("gru.bi"), v("gru.Wh")
+        gru = {"ir": {"kernel": Wi[:, :64], "bias": bi[:64]}, "iz": {"kernel": Wi[:, 64:128], "bias": bi[64:128]},
+               "in": {"kernel": Wi[:, 128:], "bias": bi[128:]}, "hr": {"kernel": Wh[:, :64]}, "hz": {"kernel": Wh[:, 64:128]},
+               "hn": {"kernel": Wh[:, 128:], "bias": v("gru.bhn")}}
+        rnn = {"GRUCell_1": gru}
+        if self.kind == "policy":
+            Wms, bms = v("head.Wms"), v("head.bms")
+            k = self.n_out
+            return {"params": {
+                "PolicyNet_0": {"GraphTransformerGNN_0": gnn, "PolicyGNNHead": head, "RNN_0": rnn},
+                "ScaleHid": {"kernel": v("head.Ws"), "bias": v("head.bs")},
+                "OutputDenseMean": {"kernel": Wms[:, :k], "bias": bms[:k]},
+                "OutputDenseStdTrans": {"kernel": Wms[:, k:], "bias": bms[k:]}}}
+        return {"params": {"GraphTransformerGNN_0": gnn, "ValueGNNHead": head, "RNN_0": rnn,
+                           "Dense_0": {"kernel": v("head.Wo"), "bias": v("head.bo")}}}

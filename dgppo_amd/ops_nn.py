@@ -1,0 +1,171 @@
+"""Torch-tensor wrappers over the network entry points of the C ABI (include/dgppo_hip.h).
+Matrices may be row-strided views (unit inner stride): (pointer, leading dimension) are passed to the kernels."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _native as N
+
+
+def _mat(t: torch.Tensor, name: str):
+    """2-D fp32 CUDA tensor with unit inner stride -> (ptr, ld, rows, cols)."""
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D, got {tuple(t.shape)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name} must have unit inner stride")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return C.c_void_p(t.data_ptr()), int(ld), int(t.shape[0]), int(t.shape[1])
+
+
+def _p(t: Optional[torch.Tensor], name="tensor", dtype=torch.float32):
+    return N.ptr(t, dtype, name)
+
+
+def dense_fwd(X, W, bias, Y, act: int = 0, accumulate: bool = False, trans_w: bool = False):
+    """Y = act(X @ W + bias)   (trans_w: X @ W.T with W stored [N, K])."""
+    xp, ldx, M, K = _mat(X, "X")
+    wp, ldw, wr, wc = _mat(W, "W")
+    yp, ldy, My, Ncol = _mat(Y, "Y")
+    Kw, Nw = (wc, wr) if trans_w else (wr, wc)
+    if Kw != K or Nw != Ncol or My != M:
+        raise ValueError(f"dense_fwd: shape mismatch X{tuple(X.shape)} W{tuple(W.shape)} trans={trans_w} Y{tuple(Y.shape)}")
+    if bias is not None:
+        N.expect_shape(bias, (Ncol,), "bias")
+    rc = N.lib().dgppo_dense_fwd(xp, ldx, wp, ldw, _p(bias, "bias"), yp, ldy, M, K, Ncol, int(act), int(accumulate),
+                                 int(trans_w), N.stream_ptr())
+    N.check(rc, "dgppo_dense_fwd")
+
+
+def dense_bwd_w(X, dY, dW, db=None):
+    """dW += X.T @ dY ; db += dY.sum(0)"""
+    xp, ldx, M, K = _mat(X, "X")
+    yp, ldy, My, Ncol = _mat(dY, "dY")
+    wp, ldw, Kw, Nw = _mat(dW, "dW")
+    if My != M or Kw != K or Nw != Ncol:
+        raise ValueError(f"dense_bwd_w: shape mismatch X{tuple(X.shape)} dY{tuple(dY.shape)} dW{tuple(dW.shape)}")
+    if db is not None:
+        N.expect_shape(db, (Ncol,), "db")
+    rc = N.lib().dgppo_dense_bwd_w(xp, ldx, yp, ldy, wp, ldw, _p(db, "db"), M, K, Ncol, N.stream_ptr())
+    N.check(rc, "dgppo_dense_bwd_w")
+
+
+def graph_feats(cfg: N.EnvCfg, agent, agent_se, agent_st, goal, obst, hits, hits_se, hits_st, env_ids, n_env, n_time,
+                Xa, Xo, efeat, emask, Fp):
+    """agent/hits are base tensors (any shape); strides are in floats."""
+    G = n_env * n_time
+    n, S = cfg.n_agents, cfg.fan_in
+    n_other = cfg.num_nodes - 1 - n
+    N.expect_shape(Xa, (G * n, Fp), "Xa")
+    if n_other > 0:
+        N.expect_shape(Xo, (G * n_other, Fp), "Xo")
+    N.expect_shape(efeat, (G * n, S, 4), "efeat")
+    N.expect_shape(emask, (G * n, S), "emask")
+    rc = N.lib().dgppo_graph_feats(
+        C.byref(cfg), C.c_void_p(agent.data_ptr()), C.c_int64(agent_se), C.c_int64(agent_st), _p(goal, "goal"),
+        _p(obst, "obst") if (obst is not None and not cfg.is_lidar) else C.c_void_p(0),
+        C.c_void_p(hits.data_ptr()) if hits is not None else C.c_void_p(0), C.c_int64(hits_se), C.c_int64(hits_st),
+        _p(env_ids, "env_ids", torch.int32), C.c_int32(n_env), C.c_int32(n_time), _p(Xa, "Xa"), _p(Xo, "Xo"),
+        _p(efeat, "efeat"), _p(emask, "emask"), C.c_int32(Fp), N.stream_ptr())
+    N.check(rc, "dgppo_graph_feats")
+
+
+def attn_fwd(cfg, F, H, Kp, qt, Xa, Xo, efeat, emask, zcat, attn, G):
+    n, S = cfg.n_agents, cfg.fan_in
+    N.expect_shape(qt, (G * n, H * F), "qt")
+    N.expect_shape(Xa, (G * n, F), "Xa")
+    N.expect_shape(zcat, (G * n, Kp), "zcat")
+    N.expect_shape(attn, (G * n, S, H), "attn")
+    rc = N.lib().dgppo_attn_fwd(C.byref(cfg), F, H, Kp, _p(qt), _p(Xa), _p(Xo), _p(efeat), _p(emask), _p(zcat), _p(attn),
+                                G, N.stream_ptr())
+    N.check(rc, "dgppo_attn_fwd")
+
+
+def attn_bwd(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo, efeat, dqt, dXa, dXo, G):
+    n = cfg.n_agents
+    N.expect_shape(dzcat, (G * n, Kp), "dzcat")
+    N.expect_shape(dqt, (G * n, H * F), "dqt")
+    if dXa is not None:
+        N.expect_shape(dXa, (G * n, F), "dXa")
+    rc = N.lib().dgppo_attn_bwd(C.byref(cfg), F, H, Kp, _p(dzcat), _p(attn), _p(qt), _p(Xa), _p(Xo), _p(efeat), _p(dqt),
+                                _p(dXa), _p(dXo), G, N.stream_ptr())
+    N.check(rc, "dgppo_attn_bwd")
+
+
+def gnn_prep(Wq, bq, Wk, Wv, bv, We, Wu, Mcat, cvec, Wout, F, Fp, D, H, Kp):
+    rc = N.lib().dgppo_gnn_prep(_p(Wq), _p(bq), _p(Wk), _p(Wv), _p(bv), _p(We), _p(Wu), _p(Mcat), _p(cvec), _p(Wout),
+                                F, Fp, D, H, Kp, N.stream_ptr())
+    N.check(rc, "dgppo_gnn_prep")
+
+
+def gnn_unprep(dMcat, dcvec, dWout, Wq, bq, Wk, dWq, dbq, dWk, dWv, dbv, dWe, dWu, F, Fp, D, H, Kp):
+    rc = N.lib().dgppo_gnn_unprep(_p(dMcat), _p(dcvec), _p(dWout), _p(Wq), _p(bq), _p(Wk), _p(dWq), _p(dbq), _p(dWk),
+                                  _p(dWv), _p(dbv), _p(dWe), _p(dWu), F, Fp, D, H, Kp, N.stream_ptr())
+    N.check(rc, "dgppo_gnn_unprep")
+
+
+def ln_relu_fwd(x, gamma, beta, y, stats):
+    M = x.shape[0]
+    N.expect_shape(x, (M, 64), "x")
+    N.expect_shape(y, (M, 64), "y")
+    rc = N.lib().dgppo_ln_relu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), M, N.stream_ptr())
+    N.check(rc, "dgppo_ln_relu_fwd")
+
+
+def ln_relu_bwd(x, y, stats, gamma, dy, dx, dgamma, dbeta):
+    M = x.shape[0]
+    rc = N.lib().dgppo_ln_relu_bwd(_p(x), _p(y), _p(stats), _p(gamma), _p(dy), _p(dx), _p(dgamma), _p(dbeta), M,
+                                   N.stream_ptr())
+    N.check(rc, "dgppo_ln_relu_bwd")
+
+
+def gru_fwd(gi, Wh, bhn, h0, hs, hprev, gates, n_seq, T, n_inner):
+    rows = n_seq * T
+    N.expect_shape(gi, (rows, 192), "gi")
+    N.expect_shape(hs, (rows, 64), "hs")
+    N.expect_shape(Wh, (64, 192), "Wh")
+    if h0 is not None:
+        N.expect_shape(h0, (n_seq, 64), "h0")
+    rc = N.lib().dgppo_gru_fwd(_p(gi), _p(Wh), _p(bhn), _p(h0), _p(hs), _p(hprev), _p(gates), n_seq, T, n_inner,
+                               N.stream_ptr())
+    N.check(rc, "dgppo_gru_fwd")
+
+
+def gru_bwd(dhs, Wh, hprev, gates, dgi, dgh, n_seq, T, n_inner):
+    rows = n_seq * T
+    N.expect_shape(dhs, (rows, 64), "dhs")
+    N.expect_shape(dgi, (rows, 192), "dgi")
+    N.expect_shape(dgh, (rows, 192), "dgh")
+    rc = N.lib().dgppo_gru_bwd(_p(dhs), _p(Wh), _p(hprev), _p(gates), _p(dgi), _p(dgh), n_seq, T, n_inner, N.stream_ptr())
+    N.check(rc, "dgppo_gru_bwd")
+
+
+def policy_head(ms, eps, action_in, action, log_pi, entropy, n_agents, mode, log_pi_old=None, adv=None, dms=None,
+                stats=None, clip_eps=0.25, coef_ent=0.01):
+    rows = ms.shape[0]
+    N.expect_shape(ms, (rows, 4), "ms")
+    rc = N.lib().dgppo_policy_head(_p(ms), _p(eps), _p(action_in), _p(action), _p(log_pi), _p(entropy), rows, n_agents,
+                                   mode, _p(log_pi_old), _p(adv), _p(dms), _p(stats), C.c_float(clip_eps),
+                                   C.c_float(coef_ent), N.stream_ptr())
+    N.check(rc, "dgppo_policy_head")
+
+
+def value_loss(v, target, dv, stats):
+    rc = N.lib().dgppo_value_loss(_p(v), _p(target), _p(dv), _p(stats), v.numel(), N.stream_ptr())
+    N.check(rc, "dgppo_value_loss")
+
+
+def mean_agents(x, y, G, n, D, backward=False):
+    rc = N.lib().dgppo_mean_agents(_p(x), _p(y), G, n, D, int(backward), N.stream_ptr())
+    N.check(rc, "dgppo_mean_agents")
+
+
+def relu_bwd(dy, y):
+    rc = N.lib().dgppo_relu_bwd(_p(dy), _p(y), C.c_int64(dy.numel()), N.stream_ptr())
+    N.check(rc, "dgppo_relu_bwd")

@@ -142,6 +142,79 @@ int32_t dgppo_env_reset(const dgppo_env_cfg* cfg, const uint64_t* seeds,
  * jax.random draw inside dist.sample(seed=key) (algo/module/policy.py:196-203).         */
 int32_t dgppo_randn(uint64_t seed, uint64_t offset, float* out, int64_t n_elem, void* stream);
 
+/* ---- networks: building blocks ------------------------------------------------------------ */
+/* All matrices row-major fp32; `ld*` = leading dimension in floats.                              */
+
+/* Y[M,N] = act(X[M,K] W[K,N] + bias) on the fp32 matrix cores; act 0 none / 1 relu; accumulate: Y += ...;
+ * trans_w: use W^T (W stored [N,K]) — the input-gradient of a Dense.  Replaces flax nn.Dense as used by
+ * dgppo/nn/mlp.py:19-22, dgppo/nn/gnn.py:86-110, dgppo/nn/rnn.py:19-21, algo/module/policy.py:67-70, value.py:41,76. */
+int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, int32_t ldw, const float* bias, float* Y,
+                        int32_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, int32_t accumulate,
+                        int32_t trans_w, void* stream);
+/* dW[K,N] += X^T dY ; db[N] += colsum(dY) (db may be NULL): the weight-gradient of a Dense
+ * (jax.grad at dgppo/algo/informarl.py:377,440 ; dgppo/algo/dgppo.py:316).                          */
+int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
+                          float* db, int32_t M, int32_t K, int32_t N, void* stream);
+
+/* Compact record -> per-graph dense features for the GNN: agent node rows Xa [G*n,Fp], other node rows
+ * Xo [G*(Ns-n),Fp], per-(agent,slot) edge features [G*n,S,4] and masks [G*n,S] (1/0).  Graph g = e*n_time + t reads
+ * agent + env*agent_se + t*agent_st (env = env_ids ? env_ids[e] : e), likewise hits.  Same arithmetic as
+ * get_graph/edge_blocks (lidar_env/base.py:227-271, lidar_spread.py:57-96, lidar_target.py:57-96, mpe twins).         */
+int32_t dgppo_graph_feats(const dgppo_env_cfg* cfg, const float* agent, int64_t agent_se, int64_t agent_st,
+                          const float* goal, const float* obst, const float* hits, int64_t hits_se, int64_t hits_st,
+                          const int32_t* env_ids, int32_t n_env, int32_t n_time, float* Xa, float* Xo, float* efeat,
+                          float* emask, int32_t Fp, void* stream);
+
+/* GraphTransformer attention in fixed-fan-in form (dgppo/nn/gnn.py:85-117; jraph.segment_softmax/segment_sum):
+ * qt [G*n,H*F] = x_i Mcat + cvec (a Dense), logits = qt . x_sender, masked softmax over the S slots of each agent,
+ * zcat [G*n,Kp] = [x_i | per head: sum a x_s (F), sum a e (4) | 1 | 0...], attn [G*n,S,H] saved for backward.       */
+int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* qt, const float* Xa,
+                       const float* Xo, const float* efeat, const float* emask, float* zcat, float* attn, int32_t G,
+                       void* stream);
+/* backward of the above: dqt [G*n,H*F]; dXa [G*n,F] / dXo [G*(Ns-n),F] written (not accumulated) when non-NULL.  */
+int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
+                       const float* attn, const float* qt, const float* Xa, const float* Xo, const float* efeat,
+                       float* dqt, float* dXa, float* dXo, int32_t G, void* stream);
+
+/* GraphTransformer parameters (flax Dense_0..4 = q,k,v,e,u; gnn.py:86-110) -> Mcat [Fp,H*Fp], cvec [H*Fp],
+ * Wout [Kp,D] used by dgppo_attn_* and the surrounding Denses; and the adjoint map (accumulates into d*).           */
+int32_t dgppo_gnn_prep(const float* Wq, const float* bq, const float* Wk, const float* Wv, const float* bv,
+                       const float* We, const float* Wu, float* Mcat, float* cvec, float* Wout, int32_t F, int32_t Fp,
+                       int32_t D, int32_t H, int32_t Kp, void* stream);
+int32_t dgppo_gnn_unprep(const float* dMcat, const float* dcvec, const float* dWout, const float* Wq, const float* bq,
+                         const float* Wk, float* dWq, float* dbq, float* dWk, float* dWv, float* dbv, float* dWe,
+                         float* dWu, int32_t F, int32_t Fp, int32_t D, int32_t H, int32_t Kp, void* stream);
+
+/* y = relu(LayerNorm_64(x)) (dgppo/nn/mlp.py:27-29; flax LayerNorm eps 1e-6); stats [M,2] = mean, rstd.          */
+int32_t dgppo_ln_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int32_t M,
+                          void* stream);
+int32_t dgppo_ln_relu_bwd(const float* x, const float* y, const float* stats, const float* gamma, const float* dy,
+                          float* dx, float* dgamma, float* dbeta, int32_t M, void* stream);
+
+/* GRU scan (dgppo/nn/rnn.py:14-30, flax GRUCell, 64 features).  gi [rows,192] = x Wi + bi precomputed; Wh [64,192]
+ * (r|z|n); sequence s at step tau lives in row ((s/n_inner)*T + tau)*n_inner + s%n_inner.  h0 [n_seq,64] or NULL.
+ * hs [rows,64]; hprev [rows,64] and gates [rows,256] are saved for the backward when non-NULL.                      */
+int32_t dgppo_gru_fwd(const float* gi, const float* Wh, const float* bhn, const float* h0, float* hs, float* hprev,
+                      float* gates, int32_t n_seq, int32_t T, int32_t n_inner, void* stream);
+/* BPTT over the T steps of every sequence: dgi [rows,192], dgh [rows,192] (then dWh = hprev^T dgh).               */
+int32_t dgppo_gru_bwd(const float* dhs, const float* Wh, const float* hprev, const float* gates, float* dgi,
+                      float* dgh, int32_t n_seq, int32_t T, int32_t n_inner, void* stream);
+
+/* tanh-Normal head (algo/module/policy.py:62-74,191-212 ; distribution.py:10-46).  ms [rows,4] = mean(2)|std_trans(2).
+ * mode 0 sample (eps [rows,2]) -> action, log_pi; 1 mode -> action = tanh(mean); 2 eval (action_in, eps = the constant
+ * entropy noise [n_agents,2]) -> log_pi, entropy and, when dms != NULL, the PPO clipped-surrogate loss gradient
+ * (informarl.py:428-438) w.r.t. ms plus stats[0..3] += sum loss, sum entropy, sum(l2>l1), sum|rho-1|.               */
+int32_t dgppo_policy_head(const float* ms, const float* eps, const float* action_in, float* action, float* log_pi,
+                          float* entropy, int32_t rows, int32_t n_agents, int32_t mode, const float* log_pi_old,
+                          const float* adv, float* dms, float* stats, float clip_eps, float coef_ent, void* stream);
+
+/* optax.l2_loss(v, target).mean() (informarl.py:374, dgppo.py:310): dv = (v-target)/count, stats[0] += sum 1/2 d^2 */
+int32_t dgppo_value_loss(const float* v, const float* target, float* dv, float* stats, int32_t count, void* stream);
+/* mean over the n agents of each graph (value.py:33): x [G,n,D] -> y [G,D]; backward: x = dy [G,D] -> y = dx [G,n,D] */
+int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_t D, int32_t backward, void* stream);
+/* dy *= (y > 0), in place                                                                                             */
+int32_t dgppo_relu_bwd(float* dy, const float* y, int64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

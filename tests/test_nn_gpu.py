@@ -1,0 +1,377 @@
+"""GPU parity of the network building blocks and of the three composed networks (HIP, via the C ABI) against the
+torch-CPU oracle in the reference's per-edge form (oracle/nn_torch.py).  fp32 tolerance: 1e-5 on O(1) outputs
+(north_star), gradients 2e-5 relative to the gradient's scale."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import env_np as E
+from oracle import nn_torch as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, tol=1e-5, name=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, f"{name}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("M,K,N,act,trans", [(1000, 64, 64, 1, False), (777, 7, 24, 0, False), (130, 48, 32, 1, False),
+                                             (64, 144, 64, 0, False), (513, 64, 192, 0, False), (300, 64, 4, 0, False),
+                                             (300, 4, 64, 0, True), (1000, 192, 64, 0, True), (257, 64, 141, 0, True)])
+def test_dense_fwd(cuda, M, K, N, act, trans):
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M + K + N)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) if trans else torch.randn(K, N, generator=g)
+    b = torch.randn(N, generator=g)
+    Y0 = torch.randn(M, N, generator=g)
+    want = X @ (W.T if trans else W) + b
+    if act:
+        want = torch.relu(want)
+    Y = torch.empty(M, N, device=cuda)
+    K_.dense_fwd(X.to(cuda), W.to(cuda), b.to(cuda), Y, act=act, trans_w=trans)
+    _close(Y, want, 2e-6 * math.sqrt(K), "dense")
+    # accumulate + strided views (column slices of wider matrices)
+    Xw = torch.zeros(M, K + 5, device=cuda)
+    Xw[:, 2:2 + K] = X.to(cuda)
+    Yw = torch.zeros(M, N + 3, device=cuda)
+    Yw[:, 1:1 + N] = Y0.to(cuda)
+    K_.dense_fwd(Xw[:, 2:2 + K], W.to(cuda), None, Yw[:, 1:1 + N], accumulate=True, trans_w=trans)
+    _close(Yw[:, 1:1 + N], Y0 + X @ (W.T if trans else W), 2e-6 * math.sqrt(K), "dense acc")
+    assert float(Yw[:, 0].abs().max()) == 0 and float(Yw[:, 1 + N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 64, 64), (999, 48, 32), (4096, 144, 64), (2000, 64, 192), (700, 8, 24),
+                                   (1500, 64, 4), (100, 32, 96)])
+def test_dense_bwd_w(cuda, M, K, N):
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M * 3 + K + N)
+    X = torch.randn(M, K, generator=g)
+    dY = torch.randn(M, N, generator=g)
+    dW = torch.zeros(K, N, device=cuda)
+    db = torch.zeros(N, device=cuda)
+    K_.dense_bwd_w(X.to(cuda), dY.to(cuda), dW, db)
+    _close(dW, X.double().T @ dY.double(), 3e-6 * math.sqrt(M), "dW")
+    _close(db, dY.double().sum(0), 3e-6 * math.sqrt(M), "db")
+
+
+def test_ln_relu(cuda):
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(0)
+    M = 1037
+    x = (torch.randn(M, 64, generator=g) * 2 + 0.3).requires_grad_()
+    p = {"scale": (torch.rand(64, generator=g) + 0.5).requires_grad_(), "bias": (torch.randn(64, generator=g) * 0.1).requires_grad_()}
+    y = torch.relu(T.layer_norm(p, x))
+    dy = torch.randn(M, 64, generator=g)
+    y.backward(dy)
+    xd = x.detach().to(cuda)
+    yd = torch.empty(M, 64, device=cuda)
+    st = torch.empty(M, 2, device=cuda)
+    K_.ln_relu_fwd(xd, p["scale"].detach().to(cuda), p["bias"].detach().to(cuda), yd, st)
+    _close(yd, y, 1e-5, "ln fwd")
+    dx = torch.empty(M, 64, device=cuda)
+    dg = torch.zeros(64, device=cuda)
+    db = torch.zeros(64, device=cuda)
+    K_.ln_relu_bwd(xd, yd, st, p["scale"].detach().to(cuda), dy.to(cuda), dx, dg, db)
+    _close(dx, x.grad, 2e-5, "ln dx")
+    _close(dg, p["scale"].grad, 2e-5, "ln dgamma")
+    _close(db, p["bias"].grad, 2e-5, "ln dbeta")
+
+
+@pytest.mark.parametrize("n_grp,T_,n_inner,use_h0", [(5, 16, 8, False), (70, 1, 3, True), (9, 7, 1, True), (130, 3, 1, False)])
+def test_gru_scan(cuda, n_grp, T_, n_inner, use_h0):
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(n_grp + T_)
+    p = T.init_gru(g)
+    p["hn"]["bias"] = torch.randn(64, generator=g) * 0.1
+    for k in p:
+        for kk in p[k]:
+            p[k][kk].requires_grad_()
+    n_seq = n_grp * n_inner
+    rows = n_seq * T_
+    x = (torch.randn(rows, 64, generator=g)).requires_grad_()      # row = (grp*T + tau)*n_inner + i
+    h0 = (torch.randn(n_seq, 64, generator=g) * 0.5).requires_grad_() if use_h0 else None
+    xs = x.view(n_grp, T_, n_inner, 64)
+    h = h0.view(n_grp, n_inner, 64) if use_h0 else torch.zeros(n_grp, n_inner, 64)
+    outs = []
+    for tau in range(T_):
+        h = T.gru_cell(p, h, xs[:, tau])
+        outs.append(h)
+    hs = torch.stack(outs, 1).reshape(rows, 64)
+    dhs = torch.randn(rows, 64, generator=g)
+    hs.backward(dhs)
+    Wi = torch.cat([p[k]["kernel"] for k in ("ir", "iz", "in")], 1).detach()
+    bi = torch.cat([p[k]["bias"] for k in ("ir", "iz", "in")]).detach()
+    Wh = torch.cat([p[k]["kernel"] for k in ("hr", "hz", "hn")], 1).detach().contiguous().to(cuda)
+    bhn = p["hn"]["bias"].detach().to(cuda)
+    gi = (x.detach() @ Wi + bi).to(cuda)
+    hs_d = torch.empty(rows, 64, device=cuda)
+    hprev = torch.empty(rows, 64, device=cuda)
+    gates = torch.empty(rows, 256, device=cuda)
+    K_.gru_fwd(gi, Wh, bhn, h0.detach().to(cuda) if use_h0 else None, hs_d, hprev, gates, n_seq, T_, n_inner)
+    _close(hs_d, hs, 1e-5, "gru hs")
+    dgi = torch.empty(rows, 192, device=cuda)
+    dgh = torch.empty(rows, 192, device=cuda)
+    K_.gru_bwd(dhs.to(cuda), Wh, hprev, gates, dgi, dgh, n_seq, T_, n_inner)
+    # dx = dgi Wi^T ; dWi = x^T dgi ; dWh = hprev^T dgh ; dbhn = colsum dgh[:,128:]
+    _close(dgi.cpu() @ Wi.T, x.grad, 2e-5, "gru dx")
+    dWi = x.detach().T @ dgi.cpu()
+    _close(dWi[:, :64], p["ir"]["kernel"].grad, 3e-5, "dWir")
+    _close(dWi[:, 128:], p["in"]["kernel"].grad, 3e-5, "dWin")
+    dWh = hprev.cpu().T @ dgh.cpu()
+    _close(dWh[:, 64:128], p["hz"]["kernel"].grad, 3e-5, "dWhz")
+    _close(dWh[:, 128:], p["hn"]["kernel"].grad, 3e-5, "dWhn")
+    _close(dgh.cpu()[:, 128:].sum(0), p["hn"]["bias"].grad, 3e-5, "dbhn")
+    _close(dgi.cpu().sum(0)[:64], p["ir"]["bias"].grad, 3e-5, "dbir")
+
+
+def test_policy_head_all_modes(cuda):
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(3)
+    n = 8
+    rows = 64 * n + 3 * n
+    ms = torch.randn(rows, 4, generator=g)
+    ms[:, :2] *= 1.5
+    ms[5, 0] = 6.0      # drives an action past the 0.999 clip -> log-cdf branch
+    ms[6, 1] = -6.0
+    eps = torch.randn(rows, 2, generator=g)
+    mean, std = ms[:, :2], torch.nn.functional.softplus(ms[:, 2:] + T.STD_INIT_INV) + T.STD_MIN
+    act_want = torch.tanh(mean + std * eps)
+    lp_want = T.tanh_normal_log_prob(act_want, mean, std)
+    msd = ms.to(cuda)
+    act = torch.empty(rows, 2, device=cuda)
+    lp = torch.empty(rows, device=cuda)
+    K_.policy_head(msd, eps.to(cuda), None, act, lp, None, n, 0)
+    _close(act, act_want, 1e-6, "sample action")
+    assert (act_want.abs() >= 0.999).any()
+    _close(lp, lp_want, 1e-5, "sample log_pi")
+    K_.policy_head(msd, None, None, act, None, None, n, 1)
+    _close(act, torch.tanh(mean), 1e-6, "mode action")
+    # eval + PPO loss gradient
+    eps_hat = torch.randn(n, 2, generator=g)
+    a_in = act_want.clone()
+    a_in[10:20] = torch.tanh(torch.randn(10, 2, generator=g))
+    lp_old = lp_want + 0.3 * torch.randn(rows, generator=g)
+    adv = torch.randn(rows, generator=g)
+    msr = ms.clone().requires_grad_()
+    mean_r, std_r = msr[:, :2], torch.nn.functional.softplus(msr[:, 2:] + T.STD_INIT_INV) + T.STD_MIN
+    lp_r = T.tanh_normal_log_prob(a_in, mean_r, std_r)
+    ent_r = T.tanh_normal_entropy(mean_r, std_r, eps_hat.repeat(rows // n, 1))
+    rho = torch.exp(lp_r - lp_old)
+    l1, l2 = -rho * adv, -torch.clamp(rho, 0.75, 1.25) * adv
+    loss = torch.maximum(l1, l2).mean() - 0.01 * ent_r.mean()
+    loss.backward()
+    lp2 = torch.empty(rows, device=cuda)
+    ent2 = torch.empty(rows, device=cuda)
+    dms = torch.empty(rows, 4, device=cuda)
+    stats = torch.zeros(8, device=cuda)
+    K_.policy_head(msd, eps_hat.to(cuda), a_in.to(cuda), None, lp2, ent2, n, 2, lp_old.to(cuda), adv.to(cuda), dms, stats, 0.25, 0.01)
+    _close(lp2, lp_r, 1e-5, "eval log_pi")
+    _close(ent2, ent_r, 1e-5, "eval entropy")
+    _close(dms, msr.grad, 2e-5, "dms")
+    s = stats.cpu()
+    _close(s[0] / rows - 0.01 * s[1] / rows, loss, 1e-5, "loss")
+    _close(s[2] / rows, (l2 > l1).float().mean(), 1e-6, "clip_frac")
+    _close(0.5 * s[3] / rows, 0.5 * (rho - 1).abs().mean(), 1e-5, "tv")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# composed networks on real graphs
+# ----------------------------------------------------------------------------------------------------------------------
+def _scene(kind, n, n_obs, n_env, T_steps, seed):
+    """roll the oracle env for T_steps with random actions; returns per-(env,t) compact records + materialised graphs."""
+    from dgppo_amd import _native as N
+    ocfg = E.EnvCfg(kind, n_agents=n, n_obs=n_obs)
+    cfg = N.make_env_cfg(kind, n, n_obs)
+    rng = np.random.default_rng(seed)
+    agent, goal, obst = E.env_reset(ocfg, rng.integers(1, 2 ** 60, size=n_env))
+    agent[:, :, :2] = (agent[:, :, :2] * 0.5 + 0.4).astype(np.float32)     # crowd them so masks vary
+    tab = E.ray_table(32)
+    hits = None
+    if ocfg.is_lidar and n_obs > 0:
+        hits, _ = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)
+    agents, hitss, graphs = [agent], [hits], [E.get_graph(ocfg, agent, goal, obst, hits)]
+    for t in range(T_steps - 1):
+        a = rng.uniform(-1, 1, size=(n_env, n, 2)).astype(np.float32)
+        out = E.env_step(ocfg, agent, goal, obst, hits, a, tab)
+        agent, hits = out["next_agent"], out["next_hits"]
+        agents.append(agent); hitss.append(hits); graphs.append(out["graph"])
+    ag = np.stack(agents, 1)                                             # [n_env, T, n, sd]
+    hi = np.stack(hitss, 1) if hits is not None else None                # [n_env, T, n, k, 2]
+    gr = {k: np.stack([g[k] for g in graphs], 1).reshape((n_env * T_steps,) + graphs[0][k].shape[1:]) for k in graphs[0]}
+    return cfg, ocfg, ag, goal, obst, hi, gr
+
+
+def _feats(cfg, ag, goal, obst, hi, dev, tag="t"):
+    from dgppo_amd import nets
+    n_env, T_steps = ag.shape[:2]
+    arena = nets.Arena(dev)
+    f = nets.GraphFeats(cfg, n_env * T_steps, arena, tag)
+    agd = torch.from_numpy(ag).to(dev)
+    hid = torch.from_numpy(hi).to(dev) if hi is not None else None
+    n, sd = cfg.n_agents, cfg.state_dim
+    f.compute(agd, T_steps * n * sd, n * sd, torch.from_numpy(goal).to(dev),
+              torch.from_numpy(obst).to(dev) if obst is not None else None,
+              hid, T_steps * n * cfg.top_k * 2, n * cfg.top_k * 2, None, n_env, T_steps)
+    f._keep = (agd, hid, arena)
+    return f
+
+
+def _grad_tree_close(net, tree, tol, skip_bk=True):
+    gt = net.to_tree(net.grads)
+    want = dict(T.tree_leaves(T.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), tree)))
+    got = dict(T.tree_leaves(T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), gt)))
+    assert set(got) == set(want)
+    gscale = max(float(v.abs().max()) for v in want.values())
+    report, bad = [], []
+    for k in sorted(want):
+        err = float((got[k].double() - want[k].double()).abs().max())
+        report.append(f"{k:70s} want_max {float(want[k].abs().max()):.3e} got_max {float(got[k].abs().max()):.3e} err {err:.3e}")
+        if skip_bk and "GraphTransformer_" in k and k.endswith("Dense_1/bias"):
+            # key bias cancels in the softmax: exact 0 here, fp noise in an autograd of the per-edge form
+            if float(got[k].abs().max()) != 0.0 or float(want[k].abs().max()) > 1e-4 * max(gscale, 1.0):
+                bad.append(k)
+            continue
+        if err > tol * max(gscale, 1e-3):
+            bad.append(k)
+    if bad:
+        print("\n".join(report))
+    assert not bad, f"gradient mismatch in {bad} (scale {gscale:.3e})"
+
+
+def _leafify(tree):
+    return T.tree_map(lambda t: t.clone().requires_grad_(), tree)
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [(E.LIDAR_SPREAD, 8, 3), (E.MPE_TARGET, 3, 3), (E.LIDAR_BICYCLE_TARGET, 4, 2),
+                                           (E.MPE_SPREAD, 3, 0)])
+def test_policy_forward_backward(cuda, kind, n, n_obs):
+    from dgppo_amd import nets, ops_nn as K_
+    n_env, T_ = 4, 16
+    cfg, ocfg, ag, goal, obst, hi, gr = _scene(kind, n, n_obs, n_env, T_, seed=kind * 10 + n)
+    tree = T.init_policy(1, cfg.node_dim)
+    # non-trivial biases / LayerNorm params so every gradient path is exercised
+    gen = torch.Generator().manual_seed(5)
+    tree = T.tree_map(lambda t: t + 0.05 * torch.randn(t.shape, generator=gen), tree)
+    # ScaleHid is 0.01 * orthogonal at init: rescale so mean / std_trans are O(0.3) and every branch is exercised
+    tree["params"]["ScaleHid"]["kernel"] = T.orthogonal(gen, 64, 64, 0.5)
+    net = nets.Net("policy", cfg, 2, 2, cuda)
+    net.load_tree(tree)
+    feats = _feats(cfg, ag, goal, obst, hi, cuda)
+    G = n_env * T_
+    act = net.forward(feats, n_seq=n_env * n, T=T_, h0=None)
+    # oracle: scan over the chunk with zero initial carry (informarl.py:409-424)
+    lt = _leafify(tree)
+    g_t = T.graph_to_torch(gr)
+    gsel = lambda t: {k: v.view((n_env, T_) + v.shape[1:])[:, t] for k, v in g_t.items()}
+    rng = torch.Generator().manual_seed(9)
+    a_in = torch.tanh(torch.randn(n_env, T_, n, 2, generator=rng))
+    eps_hat = torch.randn(n, 2, generator=rng)
+    h = torch.zeros(n_env, n, 64)
+    lps, ents, hss = [], [], []
+    for t in range(T_):
+        lp, ent, h = T.policy_eval(lt, gsel(t), a_in[:, t], h, n, eps_hat)
+        lps.append(lp); ents.append(ent); hss.append(h)
+    lp_w, ent_w, hs_w = torch.stack(lps, 1), torch.stack(ents, 1), torch.stack(hss, 1)
+    _close(act["hs"].view(n_env, T_, n, 64), hs_w, 1e-5, "policy hidden")
+    R = G * n
+    lp_old = (lp_w.detach() + 0.2 * torch.randn(n_env, T_, n, generator=rng))
+    adv = torch.randn(n_env, T_, n, generator=rng)
+    rho = torch.exp(lp_w - lp_old)
+    loss = torch.maximum(-rho * adv, -torch.clamp(rho, 0.75, 1.25) * adv).mean() - 0.01 * ent_w.mean()
+    loss.backward()
+    lp = torch.empty(R, device=cuda); ent = torch.empty(R, device=cuda)
+    dms = torch.empty(R, 4, device=cuda); stats = torch.zeros(8, device=cuda)
+    K_.policy_head(act["ms"], eps_hat.to(cuda), a_in.reshape(R, 2).to(cuda), None, lp, ent, n, 2,
+                   lp_old.reshape(R).to(cuda), adv.reshape(R).to(cuda), dms, stats, 0.25, 0.01)
+    _close(lp.view(n_env, T_, n), lp_w, 1e-5, "policy log_pi")
+    _close(ent.view(n_env, T_, n), ent_w, 1e-5, "policy entropy")
+    net.zero_grads()
+    net.backward(act, dms)
+    torch.cuda.synchronize()
+    _grad_tree_close(net, lt, 3e-5)
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [(E.LIDAR_SPREAD, 8, 3), (E.MPE_SPREAD, 3, 3)])
+def test_Vl_forward_backward(cuda, kind, n, n_obs):
+    from dgppo_amd import nets, ops_nn as K_
+    n_env, T_ = 5, 8
+    cfg, ocfg, ag, goal, obst, hi, gr = _scene(kind, n, n_obs, n_env, T_, seed=3)
+    gen = torch.Generator().manual_seed(6)
+    tree = T.tree_map(lambda t: t + 0.05 * torch.randn(t.shape, generator=gen), T.init_value(2, cfg.node_dim, 1, 2))
+    net = nets.Net("Vl", cfg, 2, 1, cuda)
+    net.load_tree(tree)
+    feats = _feats(cfg, ag, goal, obst, hi, cuda)
+    act = net.forward(feats, n_seq=n_env, T=T_, h0=None)
+    lt = _leafify(tree)
+    g_t = T.graph_to_torch(gr)
+    gsel = lambda t: {k: v.view((n_env, T_) + v.shape[1:])[:, t] for k, v in g_t.items()}
+    h = torch.zeros(n_env, 1, 64)
+    vs = []
+    for t in range(T_):
+        v, h = T.value_Vl(lt, gsel(t), h, n)
+        vs.append(v)
+    v_w = torch.stack(vs, 1)
+    _close(act["v"].view(n_env, T_), v_w, 1e-5, "Vl")
+    target = torch.randn(n_env, T_, generator=gen)
+    (0.5 * (v_w - target) ** 2).mean().backward()
+    dv = torch.empty(n_env * T_, 1, device=cuda)
+    stats = torch.zeros(8, device=cuda)
+    K_.value_loss(act["v"], target.reshape(-1, 1).to(cuda), dv, stats)
+    net.zero_grads()
+    net.backward(act, dv)
+    torch.cuda.synchronize()
+    _close(stats[0].cpu() / (n_env * T_), (0.5 * (v_w - target) ** 2).mean(), 1e-5, "Vl loss")
+    _grad_tree_close(net, lt, 3e-5)
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [(E.LIDAR_SPREAD, 8, 3), (E.LIDAR_TARGET, 3, 2)])
+def test_Vh_forward_backward(cuda, kind, n, n_obs):
+    from dgppo_amd import nets, ops_nn as K_
+    n_env, T_ = 3, 6
+    cfg, ocfg, ag, goal, obst, hi, gr = _scene(kind, n, n_obs, n_env, T_, seed=4)
+    gen = torch.Generator().manual_seed(7)
+    tree = T.tree_map(lambda t: t + 0.05 * torch.randn(t.shape, generator=gen), T.init_value(3, cfg.node_dim, 2, 1))
+    net = nets.Net("Vh", cfg, 1, 2, cuda)
+    net.load_tree(tree)
+    feats = _feats(cfg, ag, goal, obst, hi, cuda)
+    G = n_env * T_
+    h0 = torch.randn(G, n, 64, generator=gen) * 0.5          # the actor's stored carry (dgppo.py:128-134,219-220)
+    act = net.forward(feats, n_seq=G * n, T=1, h0=h0.reshape(G * n, 64).to(cuda))
+    lt = _leafify(tree)
+    v_w, _ = T.value_Vh(lt, T.graph_to_torch(gr), h0, n)
+    _close(act["v"].view(G, n, 2), v_w, 1e-5, "Vh")
+    target = torch.randn(G, n, 2, generator=gen)
+    (0.5 * (v_w - target) ** 2).mean().backward()
+    dv = torch.empty(G * n, 2, device=cuda)
+    stats = torch.zeros(8, device=cuda)
+    K_.value_loss(act["v"], target.reshape(-1, 2).to(cuda), dv, stats)
+    net.zero_grads()
+    net.backward(act, dv)
+    torch.cuda.synchronize()
+    _grad_tree_close(net, lt, 3e-5)
+
+
+def test_tree_roundtrip_and_param_counts(cuda):
+    """parameter counts of SURVEY A.9: 62 660 / 58 305 / 39 426 floats at node_dim 7."""
+    from dgppo_amd import nets, _native as N
+    cfg = N.make_env_cfg(0, 8, 3)
+    for kind, layers, n_out, count, tree in (("policy", 2, 2, 62660, T.init_policy(0, 7)),
+                                             ("Vl", 2, 1, 58305, T.init_value(0, 7, 1, 2)),
+                                             ("Vh", 1, 2, 39426, T.init_value(0, 7, 2, 1))):
+        net = nets.Net(kind, cfg, layers, n_out, cuda)
+        net.load_tree(tree)
+        back = net.to_tree()
+        leaves_a = dict(T.tree_leaves(tree))
+        leaves_b = dict(T.tree_leaves(back))
+        assert set(leaves_a) == set(leaves_b)
+        assert sum(v.numel() for v in leaves_a.values()) == count
+        for k in leaves_a:
+            np.testing.assert_array_equal(leaves_a[k].numpy(), leaves_b[k])
