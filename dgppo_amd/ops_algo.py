@@ -1,0 +1,49 @@
+"""Torch-tensor wrappers over the GAE / advantage / optimiser entry points of the C ABI (include/dgppo_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def lam_pow_table(gae_lambda: float, T: int, device) -> torch.Tensor:
+    return torch.from_numpy((np.float64(gae_lambda) ** np.arange(T + 1)).astype(np.float32)).to(device)
+
+
+def gae(costs, rewards, Vh, Vl, lam_pow, gamma: float, gae_lambda: float, Qh, Ql):
+    B, T, n, nh = costs.shape
+    N.expect_shape(rewards, (B, T), "rewards")
+    N.expect_shape(Vh, (B, T + 1, n, nh), "Vh")
+    N.expect_shape(Vl, (B, T + 1), "Vl")
+    N.expect_shape(lam_pow, (T + 1,), "lam_pow")
+    N.expect_shape(Qh, (B, T, n, nh), "Qh")
+    N.expect_shape(Ql, (B, T), "Ql")
+    rc = N.lib().dgppo_gae(N.ptr(costs), N.ptr(rewards), N.ptr(Vh), N.ptr(Vl), N.ptr(lam_pow), C.c_float(gamma),
+                           C.c_float(1 - gamma), C.c_float(1 - gae_lambda), N.ptr(Qh), N.ptr(Ql), B, T, n, nh,
+                           N.stream_ptr())
+    N.check(rc, "dgppo_gae")
+
+
+def advantage(Ql, Vl, Vh, dt, alpha, cbf_eps, cbf_weight, adv, stats):
+    B, T1, n, nh = Vh.shape
+    T = T1 - 1
+    N.expect_shape(Ql, (B, T), "Ql")
+    N.expect_shape(Vl, (B, T + 1), "Vl")
+    N.expect_shape(adv, (B, T, n), "adv")
+    rc = N.lib().dgppo_advantage(N.ptr(Ql), N.ptr(Vl), N.ptr(Vh), C.c_float(dt), C.c_float(alpha), C.c_float(cbf_eps),
+                                 C.c_float(cbf_weight), N.ptr(adv), N.ptr(stats), B, T, n, nh, N.stream_ptr())
+    N.check(rc, "dgppo_advantage")
+
+
+def clip_adam_step(params, grads, m, v, state, lr, max_norm, b1=0.9, b2=0.999, eps=1e-8):
+    n = params.numel()
+    for t, nm in ((grads, "grads"), (m, "m"), (v, "v")):
+        N.expect_shape(t, (n,), nm)
+    N.expect_shape(state, (8,), "state")
+    rc = N.lib().dgppo_clip_adam_step(N.ptr(params), N.ptr(grads), N.ptr(m), N.ptr(v), C.c_int64(n), N.ptr(state),
+                                      C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(max_norm),
+                                      N.stream_ptr())
+    N.check(rc, "dgppo_clip_adam_step")

@@ -215,6 +215,24 @@ int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_
 /* dy *= (y > 0), in place                                                                                             */
 int32_t dgppo_relu_bwd(float* dy, const float* y, int64_t count, void* stream);
 
+/* ---- GAE, advantage, optimiser ---------------------------------------------------------------- */
+
+/* compute_dec_ocp_gae (dgppo/algo/utils.py:11-79) for B envs (env-major): costs [B,T,n,nh], rewards [B,T] (l = -reward),
+ * Vh [B,T+1,n,nh], Vl [B,T+1], lam_pow [T+1] = lambda^i  ->  Qh [B,T,n,nh], Ql [B,T].                                  */
+int32_t dgppo_gae(const float* costs, const float* rewards, const float* Vh, const float* Vl, const float* lam_pow,
+                  float gamma, float one_minus_gamma, float one_minus_lam, float* Qh, float* Ql, int32_t B, int32_t T,
+                  int32_t n, int32_t nh, void* stream);
+/* advantage block (dgppo/algo/dgppo.py:239-259): per-env normalised Ql-Vl, CBF derivative, safe gate, schedule weight
+ * -> adv [B,T,n] (already negated); stats[0] += number of safe (t, agent) pairs (eval/safe_data numerator).         */
+int32_t dgppo_advantage(const float* Ql, const float* Vl, const float* Vh, float dt, float alpha, float cbf_eps,
+                        float cbf_weight, float* adv, float* stats, int32_t B, int32_t T, int32_t n, int32_t nh,
+                        void* stream);
+/* compute_norm_and_clip + has_any_nan_or_inf (dgppo/trainer/utils.py:89-118) and optax.apply_if_finite(adam)
+ * (dgppo/algo/informarl.py:131-137) on one flat buffer.  state [8] lives on the device:
+ * [0..1] scratch, [2] adam count, [3] total steps, [4] last grad norm, [5] last non-finite flag.                   */
+int32_t dgppo_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float* state, float lr,
+                             float b1, float b2, float eps, float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

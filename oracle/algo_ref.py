@@ -1,0 +1,89 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path (dgppo_amd/).
+
+CPU restatement of the reference's algorithm-level arithmetic: Dec-OCP GAE, advantage/CBF merge, grad clip + Adam with
+apply_if_finite, and (torch autograd) the three DGPPO losses.  Citations are file:line under /root/reference.
+
+PARITY UNPINNED w.r.t. outputs of the reference (jax/optax not installable offline); pinned by the closed-form
+tests in tests/test_oracle_algo.py (textbook GAE recursion, lambda in {0,1}, Adam hand calculation).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+f32 = np.float32
+
+
+def compute_dec_ocp_gae(Tah_hs, T_l, Tp1ah_Vh, Tp1_Vl, disc_gamma, gae_lambda):
+    """dgppo/algo/utils.py:11-79, literal (one env).  Returns Qh [T,a,nh], Ql [T]."""
+    Tah_hs = np.asarray(Tah_hs, f32); T_l = np.asarray(T_l, f32)
+    Tp1ah_Vh = np.asarray(Tp1ah_Vh, f32); Tp1_Vl = np.asarray(Tp1_Vl, f32)
+    T, n_agent, nh = Tah_hs.shape
+    g = f32(disc_gamma)
+    omg = f32(1 - disc_gamma)
+    Vhs_row = np.zeros((T + 1, n_agent, nh), f32); Vhs_row[0] = Tp1ah_Vh[-1]
+    Vl_row = np.zeros((T + 1, n_agent), f32); Vl_row[0] = Tp1_Vl[-1]
+    coeffs = np.zeros(T + 1, f32); coeffs[0] = 1.0
+    Qs = np.zeros((T, n_agent, nh + 1), f32)
+    for t in range(T - 1, -1, -1):        # lax.scan(reverse=True) over ts = arange(T)[::-1] => ii = T-1-t
+        ii = T - 1 - t
+        hs, l, Vhs, Vl = Tah_hs[t], T_l[t], Tp1ah_Vh[t], Tp1_Vl[t]
+        mask = (np.arange(T + 1) < ii + 1)
+        h_disc = hs.max(-1)
+        disc_to_h = (omg * h_disc[None, :, None] + g * Vhs_row).astype(f32)
+        Vhs_row = (mask[:, None, None] * np.maximum(hs[None], disc_to_h)).astype(f32)
+        Vl_row = (mask[:, None] * (l + g * Vl_row)).astype(f32)
+        cat = np.concatenate([Vhs_row, Vl_row[:, :, None]], axis=-1)
+        Qs[t] = np.einsum("jak,j->ak", cat.astype(np.float64), coeffs.astype(np.float64)).astype(f32)
+        Vhs_row[ii + 1] = Vhs
+        Vl_row[ii + 1] = Vl
+        coeffs = np.roll(coeffs, 1)
+        coeffs[0] = f32(gae_lambda) ** f32(ii + 1)
+        coeffs[1] = (f32(gae_lambda) ** f32(ii)) * f32(1 - gae_lambda)
+    return Qs[:, :, :nh], Qs[:, 0, nh]
+
+
+def gae_batch(costs, rewards, Vh, Vl, gamma, lam):
+    out = [compute_dec_ocp_gae(costs[b], -rewards[b], Vh[b], Vl[b], gamma, lam) for b in range(costs.shape[0])]
+    return np.stack([o[0] for o in out]), np.stack([o[1] for o in out])
+
+
+def advantage(Ql, Vl, Vh, dt, alpha, cbf_eps, cbf_weight):
+    """dgppo/algo/dgppo.py:239-259.  Ql [B,T], Vl [B,T+1], Vh [B,T+1,n,nh] -> A [B,T,n], safe_data."""
+    Al = Ql - Vl[:, :-1]
+    Al = (Al - Al.mean(axis=1, keepdims=True)) / (Al.std(axis=1, keepdims=True) + 1e-8)
+    n = Vh.shape[2]
+    Ala = np.repeat(Al[:, :, None], n, axis=-1)
+    deriv = (Vh[:, 1:] - Vh[:, :-1]) / dt + alpha * Vh[:, :-1]
+    Acbf = np.maximum(deriv + cbf_eps, 0)
+    safe = (deriv <= 0).min(axis=-1)
+    A = np.where(safe, Ala, 0.0) + Acbf.max(axis=-1) * cbf_weight
+    return (-A).astype(f32), float(safe.mean())
+
+
+def cbf_weight_schedule(cbf_weight, step, train_steps, enabled=True):
+    """optax.piecewise_constant_schedule(init, {0.5*steps: 2, 0.75*steps: 2}) (dgppo.py:73-80)."""
+    if not enabled:
+        return cbf_weight
+    w = cbf_weight
+    if step >= int(train_steps * 0.5):
+        w *= 2
+    if step >= int(train_steps * 0.75):
+        w *= 2
+    return w
+
+
+def clip_adam(p, g, m, v, count, lr, max_norm, b1=0.9, b2=0.999, eps=1e-8):
+    """trainer/utils.py:109-118 + optax.apply_if_finite(adam).  float64 reference; returns (p, m, v, count, norm, bad)."""
+    p, g, m, v = (np.asarray(x, np.float64) for x in (p, g, m, v))
+    bad = not np.all(np.isfinite(g))
+    norm = float(np.sqrt(np.sum(g * g))) if not bad else float("nan")
+    if bad:
+        return p, m, v, count, norm, True
+    gc = g / max(max_norm, norm) * max_norm
+    m = b1 * m + (1 - b1) * gc
+    v = b2 * v + (1 - b2) * gc * gc
+    count += 1
+    p = p - lr * (m / (1 - b1 ** count)) / (np.sqrt(v / (1 - b2 ** count)) + eps)
+    return p, m, v, count, norm, False

@@ -1,0 +1,68 @@
+"""GPU parity of GAE / advantage / clip+Adam (HIP via the C ABI) against oracle/algo_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import algo_ref as A
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,T,n,nh", [(7, 128, 8, 2), (3, 16, 3, 2), (2, 128, 16, 2), (4, 33, 1, 3)])
+def test_gae(cuda, B, T, n, nh):
+    from dgppo_amd import ops_algo as O
+    r = np.random.default_rng(B + T)
+    costs = r.uniform(-1, 1, size=(B, T, n, nh)).astype(np.float32)
+    rew = (-r.uniform(0, 0.02, size=(B, T))).astype(np.float32)
+    Vh = r.uniform(-1, 1, size=(B, T + 1, n, nh)).astype(np.float32)
+    Vl = r.uniform(0, 1, size=(B, T + 1)).astype(np.float32)
+    Qh_w, Ql_w = A.gae_batch(costs, rew, Vh, Vl, 0.99, 0.95)
+    d = lambda x: torch.from_numpy(x).to(cuda)
+    Qh = torch.empty(B, T, n, nh, device=cuda)
+    Ql = torch.empty(B, T, device=cuda)
+    O.gae(d(costs), d(rew), d(Vh), d(Vl), O.lam_pow_table(0.95, T, cuda), 0.99, 0.95, Qh, Ql)
+    np.testing.assert_allclose(Qh.cpu().numpy(), Qh_w, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(Ql.cpu().numpy(), Ql_w, rtol=0, atol=1e-5)
+
+
+def test_advantage(cuda):
+    from dgppo_amd import ops_algo as O
+    r = np.random.default_rng(5)
+    B, T, n, nh = 9, 128, 8, 2
+    Ql = r.normal(size=(B, T)).astype(np.float32)
+    Vl = r.normal(size=(B, T + 1)).astype(np.float32)
+    Vh = (r.normal(size=(B, T + 1, n, nh)) * 0.02 - 0.03).astype(np.float32)
+    want, safe = A.advantage(Ql, Vl, Vh, 0.03, 10.0, 1e-2, 2.0)
+    d = lambda x: torch.from_numpy(x).to(cuda)
+    adv = torch.empty(B, T, n, device=cuda)
+    stats = torch.zeros(8, device=cuda)
+    O.advantage(d(Ql), d(Vl), d(Vh), 0.03, 10.0, 1e-2, 2.0, adv, stats)
+    got = adv.cpu().numpy()
+    # the safe gate is a hard threshold on a fp32 quantity: allow a handful of borderline flips, everything else 1e-5
+    bad = np.abs(got - want) > 1e-5 * np.maximum(1, np.abs(want))
+    assert bad.mean() < 1e-3, bad.mean()
+    assert abs(stats[0].item() / (B * T * n) - safe) < 1e-3
+    assert 0.05 < safe < 0.95
+
+
+def test_clip_adam_matches_optax_semantics(cuda):
+    from dgppo_amd import ops_algo as O
+    r = np.random.default_rng(0)
+    n = 62660
+    p = r.normal(size=n).astype(np.float32)
+    pd = torch.from_numpy(p.copy()).to(cuda)
+    m = torch.zeros(n, device=cuda); v = torch.zeros(n, device=cuda); st = torch.zeros(8, device=cuda)
+    pr, mr, vr, cr = p.astype(np.float64), np.zeros(n), np.zeros(n), 0
+    for k in range(4):
+        g = (r.normal(size=n) * (0.001 if k == 1 else 0.05)).astype(np.float32)     # k=1: below max_norm -> no clipping
+        if k == 2:
+            g[123] = np.inf                                                            # skipped step
+        O.clip_adam_step(pd, torch.from_numpy(g).to(cuda), m, v, st, 3e-4, 2.0)
+        pr, mr, vr, cr, norm, bad = A.clip_adam(pr, g, mr, vr, cr, 3e-4, 2.0)
+        s = st.cpu().numpy()
+        assert s[5] == float(bad) and s[2] == cr and s[3] == k + 1
+        if not bad:
+            np.testing.assert_allclose(s[4], norm, rtol=1e-5)
+        np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(m.cpu().numpy(), mr, rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=1e-4, atol=1e-10)

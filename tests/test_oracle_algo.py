@@ -1,0 +1,85 @@
+"""Closed-form checks that pin oracle/algo_ref.py (CPU only)."""
+import numpy as np
+
+from oracle import algo_ref as A
+
+
+def _rand(T=12, n=3, nh=2, seed=0):
+    r = np.random.default_rng(seed)
+    return (r.normal(size=(T, n, nh)).astype(np.float32), r.normal(size=T).astype(np.float32),
+            r.normal(size=(T + 1, n, nh)).astype(np.float32), r.normal(size=T + 1).astype(np.float32))
+
+
+def test_Ql_equals_textbook_gae_plus_V():
+    hs, l, Vh, Vl = _rand()
+    g, lam = 0.99, 0.95
+    Qh, Ql = A.compute_dec_ocp_gae(hs, l, Vh, Vl, g, lam)
+    T = len(l)
+    adv = np.zeros(T)
+    nxt = 0.0
+    for t in range(T - 1, -1, -1):
+        delta = l[t] + g * Vl[t + 1] - Vl[t]
+        nxt = delta + g * lam * nxt
+        adv[t] = nxt
+    np.testing.assert_allclose(Ql, adv + Vl[:-1], rtol=2e-5, atol=2e-5)
+
+
+def test_lambda_limits():
+    hs, l, Vh, Vl = _rand(T=6)
+    g = 0.9
+    Qh0, Ql0 = A.compute_dec_ocp_gae(hs, l, Vh, Vl, g, 0.0)       # lambda = 0: one-step bootstrap
+    np.testing.assert_allclose(Ql0, l + g * Vl[1:], rtol=1e-5, atol=1e-6)
+    hm = hs.max(-1, keepdims=True)
+    np.testing.assert_allclose(Qh0, np.maximum(hs, (1 - g) * hm + g * Vh[1:]), rtol=1e-5, atol=1e-6)
+    Qh1, Ql1 = A.compute_dec_ocp_gae(hs, l, Vh, Vl, g, 1.0)       # lambda = 1: Monte-Carlo to the horizon
+    ret = Vl[-1]
+    rh = Vh[-1]
+    for t in range(len(l) - 1, -1, -1):
+        ret = l[t] + g * ret
+        rh = np.maximum(hs[t], (1 - g) * hs[t].max(-1, keepdims=True) + g * rh)
+        np.testing.assert_allclose(Ql1[t], ret, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Qh1[t], rh, rtol=1e-5, atol=1e-6)
+
+
+def test_constant_costs_fixed_point():
+    T, n, nh = 8, 2, 2
+    hs = np.full((T, n, nh), 0.3, np.float32)
+    Vh = np.full((T + 1, n, nh), 0.3, np.float32)
+    Qh, _ = A.compute_dec_ocp_gae(hs, np.zeros(T, np.float32), Vh, np.zeros(T + 1, np.float32), 0.99, 0.95)
+    np.testing.assert_allclose(Qh, 0.3, rtol=1e-5)     # max(h, (1-g) h + g h) = h, lambda weights sum to 1
+
+
+def test_advantage_block():
+    r = np.random.default_rng(1)
+    B, T, n, nh = 3, 10, 2, 2
+    Ql = r.normal(size=(B, T)).astype(np.float32)
+    Vl = r.normal(size=(B, T + 1)).astype(np.float32)
+    Vh = (r.normal(size=(B, T + 1, n, nh)) * 0.02 - 0.03).astype(np.float32)
+    Aout, safe = A.advantage(Ql, Vl, Vh, 0.03, 10.0, 1e-2, 1.0)
+    Al = Ql - Vl[:, :-1]
+    Al = (Al - Al.mean(1, keepdims=True)) / (Al.std(1, keepdims=True) + 1e-8)
+    deriv = (Vh[:, 1:] - Vh[:, :-1]) / 0.03 + 10 * Vh[:, :-1]
+    assert 0 < safe < 1
+    for b, t, a in [(0, 0, 0), (1, 5, 1), (2, 9, 0)]:
+        s = np.all(deriv[b, t, a] <= 0)
+        want = -((Al[b, t] if s else 0.0) + max(np.maximum(deriv[b, t, a] + 1e-2, 0)))
+        np.testing.assert_allclose(Aout[b, t, a], want, rtol=1e-5, atol=1e-6)
+    assert A.cbf_weight_schedule(1.0, 49, 100) == 1.0 and A.cbf_weight_schedule(1.0, 50, 100) == 2.0
+    assert A.cbf_weight_schedule(1.0, 75, 100) == 4.0
+
+
+def test_adam_three_steps_hand_calculation():
+    p, m, v, c = np.array([1.0]), np.zeros(1), np.zeros(1), 0
+    lr = 0.1
+    # max_norm large: no clipping; Adam with constant gradient moves by lr each step (m_hat = g, sqrt(v_hat) = |g|)
+    for k in range(3):
+        p, m, v, c, norm, bad = A.clip_adam(p, np.array([0.5]), m, v, c, lr, 1e9)
+        np.testing.assert_allclose(p, 1.0 - lr * (k + 1), rtol=1e-6)
+    assert c == 3 and not bad and abs(norm - 0.5) < 1e-12
+    # clipping: g = [3, 4] (norm 5) with max_norm 2 -> scaled by 2/5
+    p2, m2, v2, c2, norm, _ = A.clip_adam(np.zeros(2), np.array([3.0, 4.0]), np.zeros(2), np.zeros(2), 0, lr, 2.0)
+    np.testing.assert_allclose(m2, 0.1 * np.array([1.2, 1.6]))
+    assert norm == 5.0
+    # non-finite gradient: apply_if_finite skips the step and leaves the inner state untouched
+    p3, m3, v3, c3, _, bad = A.clip_adam(p2, np.array([np.nan, 1.0]), m2, v2, c2, lr, 2.0)
+    assert bad and c3 == c2 and np.array_equal(p3, p2) and np.array_equal(m3, m2)
