@@ -1,0 +1,308 @@
+"""Batched DGPPO engine: rollout collection and the update, orchestrating the HIP kernels (no torch arithmetic on the
+hot path — torch tensors are storage, copies/transposes are data movement).
+
+Reference behaviour reproduced (file:line relative to /root/reference):
+  rollout / test_rollout            dgppo/trainer/utils.py:22-86   (pre-step carry stored when stochastic, post-step when det)
+  DGPPO.update / update_inner       dgppo/algo/dgppo.py:136-294
+  update_Vl / update_policy         dgppo/algo/informarl.py:357-457
+  update_Vh                         dgppo/algo/dgppo.py:296-321
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import nets
+from . import ops_algo as OA
+from . import ops_env as OE
+from . import ops_nn as K
+
+
+@dataclasses.dataclass
+class Hyper:
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_eps: float = 0.25
+    coef_ent: float = 1e-2
+    max_grad_norm: float = 2.0
+    lr_actor: float = 3e-4
+    lr_Vl: float = 1e-3
+    lr_Vh: float = 1e-3
+    batch_size: int = 16384
+    rnn_step: int = 16
+    alpha: float = 10.0
+    cbf_eps: float = 1e-2
+    cbf_weight: float = 1.0
+    cbf_schedule: bool = True
+    train_steps: int = 100000
+    actor_gnn_layers: int = 2
+    Vl_gnn_layers: int = 2
+    Vh_gnn_layers: int = 1
+
+
+class RolloutData:
+    """Compact rollout record (SURVEY §7 'compact rollout storage'): time-major while collecting, env-major afterwards."""
+
+    def __init__(self, cfg: N.EnvCfg, B: int, T: int, device, stochastic: bool):
+        n, sd = cfg.n_agents, cfg.state_dim
+        self.cfg, self.B, self.T, self.stochastic = cfg, B, T, stochastic
+        self.has_hits = cfg.is_lidar and cfg.n_obs > 0
+        z = lambda *s: torch.empty(*s, device=device)
+        self.agent_tm = z(T + 1, B, n, sd)
+        self.hits_tm = z(T + 1, B, n, cfg.top_k, 2) if self.has_hits else None
+        self.goal = z(B, cfg.n_goals, sd)
+        self.obst = z(B, cfg.n_obs, cfg.obst_stride) if cfg.n_obs > 0 else None
+        self.action_tm = z(T, B, n, 2)
+        self.log_pi_tm = z(T, B, n) if stochastic else None
+        self.rnn_tm = z(T + 1, B, n, nets.HID)
+        self.reward_tm = z(T, B)
+        self.cost_tm = z(T, B, n, 2)
+        self._env_major = False
+
+    def finalize(self):
+        """time-major -> env-major copies (pure data movement)."""
+        if self._env_major:
+            return self
+        tr = lambda x: x.transpose(0, 1).contiguous()
+        self.agent = tr(self.agent_tm)                      # [B, T+1, n, sd]
+        self.hits = tr(self.hits_tm) if self.has_hits else None
+        self.actions = tr(self.action_tm)                   # [B, T, n, 2]
+        self.log_pis = tr(self.log_pi_tm) if self.stochastic else None
+        rnn = tr(self.rnn_tm)                               # [B, T+1, n, 64]
+        # stored carry of step t: pre-step (rollout, trainer/utils.py:46-51) or post-step (test_rollout, :71-77)
+        self.rnn_states = rnn[:, :self.T] if self.stochastic else rnn[:, 1:]
+        self.rewards = tr(self.reward_tm)                   # [B, T]
+        self.costs = tr(self.cost_tm)                       # [B, T, n, 2]
+        self._env_major = True
+        return self
+
+
+class OptState:
+    def __init__(self, n: int, device):
+        self.m = torch.zeros(n, device=device)
+        self.v = torch.zeros(n, device=device)
+        self.state = torch.zeros(8, device=device)
+
+
+class Engine:
+    def __init__(self, cfg: N.EnvCfg, hyper: Hyper, device, T: int = 128,
+                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, prepass_graphs: int = 1 << 16):
+        self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
+        self.n_cost = 2
+        self.policy = nets.Net("policy", cfg, hyper.actor_gnn_layers, 2, device)
+        self.Vl = nets.Net("Vl", cfg, hyper.Vl_gnn_layers, 1, device)
+        self.Vh = nets.Net("Vh", cfg, hyper.Vh_gnn_layers, self.n_cost, device)
+        self.opt = {k: OptState(net.layout.size, device) for k, net in self.nets.items()}
+        self.arena = nets.Arena(device)
+        self.allreduce = allreduce
+        self.prepass_graphs = prepass_graphs
+        self.ray_cos, self.ray_sin = (OE.ray_tables(cfg.n_rays, device) if cfg.is_lidar else (None, None))
+        self.lam_pow = OA.lam_pow_table(hyper.gae_lambda, T, device)
+        # the constant entropy noise of SURVEY A.7 (distribution.py:40: seed drawn once at trace time)
+        self.eps_hat = torch.zeros(cfg.n_agents, 2, device=device)
+        self.stats = torch.zeros(4, 8, device=device)
+        self.grad_hook: Optional[Callable[[str, nets.Net, int], None]] = None   # (net name, net, minibatch) before the optimiser
+        self._mb = 0
+
+    @property
+    def nets(self) -> Dict[str, nets.Net]:
+        return {"policy": self.policy, "Vl": self.Vl, "Vh": self.Vh}
+
+    def set_entropy_noise(self, seed: int):
+        OE.randn(seed, 0, self.eps_hat.view(-1))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # rollout
+    # ------------------------------------------------------------------------------------------------------------------
+    def _feats_at(self, tag, agent_slab, hits_slab, goal, obst, B):
+        """graph features of B dense [B, n, sd] states."""
+        cfg = self.cfg
+        f = nets.GraphFeats(cfg, B, self.arena, tag)
+        n, sd = cfg.n_agents, cfg.state_dim
+        f.compute(agent_slab, n * sd, 0, goal, obst, hits_slab, n * cfg.top_k * 2, 0, None, B, 1)
+        return f
+
+    def rollout(self, seeds: torch.Tensor, stochastic: bool, noise_seed: int = 0) -> RolloutData:
+        cfg, T = self.cfg, self.T
+        B = int(seeds.shape[0])
+        n = cfg.n_agents
+        ro = RolloutData(cfg, B, T, self.device, stochastic)
+        OE.env_reset(cfg, seeds, ro.agent_tm[0], ro.goal, ro.obst)
+        if ro.has_hits:
+            OE.env_step(cfg, ro.agent_tm[0], None, ro.goal, ro.obst, None, self.ray_cos, self.ray_sin, None, ro.hits_tm[0],
+                        None, None, None)
+        ro.rnn_tm[0].zero_()                                   # init_rnn_state = zeros (informarl.py:115-124)
+        eps = None
+        if stochastic:
+            eps = self.arena.get("ro.eps", T, B * n, 2)
+            OE.randn(noise_seed, 0, eps.view(-1))
+        for t in range(T):
+            hits_t = ro.hits_tm[t] if ro.has_hits else None
+            feats = self._feats_at("ro", ro.agent_tm[t], hits_t, ro.goal, ro.obst, B)
+            act = self.policy.forward(feats, n_seq=B * n, T=1, h0=ro.rnn_tm[t].view(B * n, nets.HID), tag="ro",
+                                      hs_out=ro.rnn_tm[t + 1].view(B * n, nets.HID), train=False)
+            a_t = ro.action_tm[t].view(B * n, 2)
+            if stochastic:
+                K.policy_head(act["ms"], eps[t], None, a_t, ro.log_pi_tm[t].view(B * n), None, n, 0)
+            else:
+                K.policy_head(act["ms"], None, None, a_t, None, None, n, 1)
+            OE.env_step(cfg, ro.agent_tm[t], ro.action_tm[t], ro.goal, ro.obst, hits_t, self.ray_cos, self.ray_sin,
+                        ro.agent_tm[t + 1], ro.hits_tm[t + 1] if ro.has_hits else None, ro.reward_tm[t], ro.cost_tm[t], None)
+        return ro
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # value pre-passes (dgppo.py:204-229, 262-264)
+    # ------------------------------------------------------------------------------------------------------------------
+    def _block_feats(self, tag, ro: RolloutData, e0, Eb, t0, n_time, env_ids=None):
+        cfg = self.cfg
+        n, sd, T1 = cfg.n_agents, cfg.state_dim, self.T + 1
+        f = nets.GraphFeats(cfg, Eb * n_time, self.arena, tag)
+        agent = ro.agent[e0:, t0] if env_ids is None else ro.agent[:, t0]
+        hits = None
+        if ro.has_hits:
+            hits = ro.hits[e0:, t0] if env_ids is None else ro.hits[:, t0]
+        goal = ro.goal[e0:] if env_ids is None else ro.goal
+        obst = None
+        if ro.obst is not None:
+            obst = ro.obst[e0:] if env_ids is None else ro.obst
+        f.compute(agent, T1 * n * sd, n * sd, goal, obst, hits, T1 * n * cfg.top_k * 2, n * cfg.top_k * 2, env_ids, Eb, n_time)
+        return f
+
+    def values_prepass(self, ro: RolloutData, want_Vl: bool):
+        """-> Vl [B,T+1] (or None), Vh [B,T+1,n,nh] of one rollout, with the reference's carry conventions."""
+        cfg, T, B = self.cfg, self.T, ro.B
+        n, nh, H = cfg.n_agents, self.n_cost, nets.HID
+        Vl_buf = torch.empty(B, T + 1, device=self.device) if want_Vl else None
+        Vh_buf = torch.empty(B, T + 1, n, nh, device=self.device)
+        block = max(1, min(B, self.prepass_graphs // (T + 1)))
+        for e0 in range(0, B, block):
+            Eb = min(block, B - e0)
+            feats = self._block_feats("pre", ro, e0, Eb, 0, T + 1)
+            if want_Vl:
+                act = self.Vl.forward(feats, n_seq=Eb, T=T + 1, h0=None, tag="pre", train=False)
+                Vl_buf[e0:e0 + Eb].copy_(act["v"].view(Eb, T + 1))
+            # final carry: actor GRU on next_graph[-1] from rnn_states[-1] (dgppo.py:222-226)
+            fin = self._block_feats("fin", ro, e0, Eb, T, 1)
+            h_last = self.arena.get("pre.hlast", Eb * n, H)
+            h_last.view(Eb, n, H).copy_(ro.rnn_states[e0:e0 + Eb, T - 1])
+            h0_all = self.arena.get("pre.h0all", Eb, T + 1, n, H)
+            hstar = self.arena.get("pre.hstar", Eb * n, H)
+            self.policy.forward(fin, n_seq=Eb * n, T=1, h0=h_last, tag="fin", hs_out=hstar, train=False)
+            h0_all[:, :T].copy_(ro.rnn_states[e0:e0 + Eb])
+            h0_all[:, T].copy_(hstar.view(Eb, n, H))
+            act = self.Vh.forward(feats, n_seq=Eb * (T + 1) * n, T=1, h0=h0_all.view(-1, H), tag="pre", train=False)
+            Vh_buf[e0:e0 + Eb].copy_(act["v"].view(Eb, T + 1, n, nh))
+        return Vl_buf, Vh_buf
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # update
+    # ------------------------------------------------------------------------------------------------------------------
+    def cbf_weight_at(self, step: int) -> float:
+        hp = self.hp
+        w = hp.cbf_weight
+        if hp.cbf_schedule:  # optax.piecewise_constant_schedule (dgppo.py:73-80)
+            if step >= int(hp.train_steps * 0.5):
+                w *= 2
+            if step >= int(hp.train_steps * 0.75):
+                w *= 2
+        return w
+
+    def _opt_step(self, name: str, lr: float):
+        net, opt = self.nets[name], self.opt[name]
+        if self.allreduce is not None:
+            self.allreduce(net.grads)
+        if self.grad_hook is not None:
+            self.grad_hook(name, net, self._mb)
+        OA.clip_adam_step(net.params, net.grads, opt.m, opt.v, opt.state, lr, self.hp.max_grad_norm)
+        net.prepare()
+
+    def targets(self, ro: RolloutData, det: RolloutData, step: int):
+        """Vl/Vh pre-passes, the two GAEs and the advantage merge (dgppo.py:204-273)."""
+        cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
+        n, nh = cfg.n_agents, self.n_cost
+        Vl, Vh = self.values_prepass(ro, want_Vl=True)
+        _, Vh_det = self.values_prepass(det, want_Vl=False)
+        dev = self.device
+        Qh = torch.empty(B, T, n, nh, device=dev)
+        Ql = torch.empty(B, T, device=dev)
+        OA.gae(ro.costs, ro.rewards, Vh, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh, Ql)
+        Qh_det = torch.empty(B, T, n, nh, device=dev)
+        Ql_det = torch.empty(B, T, device=dev)
+        OA.gae(det.costs, det.rewards, Vh_det, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh_det, Ql_det)
+        adv = torch.empty(B, T, n, device=dev)
+        self.stats.zero_()
+        OA.advantage(Ql, Vl, Vh, cfg.dt, hp.alpha, hp.cbf_eps, self.cbf_weight_at(step), adv, self.stats[3])
+        return dict(Vl=Vl, Vh=Vh, Vh_det=Vh_det, Ql=Ql, Qh=Qh, Qh_det=Qh_det, adv=adv)
+
+    def update(self, ro: RolloutData, det: RolloutData, step: int, perm: np.ndarray) -> dict:
+        cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
+        n, nh, H = cfg.n_agents, self.n_cost, nets.HID
+        ro.finalize()
+        det.finalize()
+        assert B * T >= hp.batch_size, "n_env_train * T must be >= batch_size (dgppo.py:153)"
+        Eb = hp.batch_size // T
+        assert B % Eb == 0 and T % hp.rnn_step == 0, "B % (batch_size // T) == 0 and T % rnn_step == 0 required (SURVEY A.11)"
+        C = T // hp.rnn_step
+        tg = self.targets(ro, det, step)
+        idx_all = torch.from_numpy(np.ascontiguousarray(perm.astype(np.int64))).to(self.device)
+        n_mb = B // Eb
+        G = Eb * T
+        R = G * n
+        for mb in range(n_mb):
+            idx = idx_all[mb * Eb:(mb + 1) * Eb]
+            idx32 = idx.to(torch.int32)
+            self.stats[:3].zero_()
+            self._mb = mb
+            feats = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=idx32)
+            # ---- Vl (informarl.py:357-385): chunks of rnn_step with zero initial carry
+            act = self.Vl.forward(feats, n_seq=Eb * C, T=hp.rnn_step, h0=None, tag="tr")
+            dv = self.arena.get("mb.dv", G, 1)
+            Ql_mb = tg["Ql"].index_select(0, idx)
+            K.value_loss(act["v"], Ql_mb.view(G, 1), dv, self.stats[0])
+            self.Vl.zero_grads()
+            self.Vl.backward(act, dv)
+            self._opt_step("Vl", hp.lr_Vl)
+            # ---- Vh on the deterministic rollout with its stored carry (dgppo.py:296-321)
+            feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=idx32)
+            h0 = det.rnn_states.index_select(0, idx).view(R, H)
+            act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0, tag="tr")
+            dvh = self.arena.get("mb.dvh", R, nh)
+            K.value_loss(act["v"], tg["Qh_det"].index_select(0, idx).view(R, nh), dvh, self.stats[1])
+            self.Vh.zero_grads()
+            self.Vh.backward(act, dvh)
+            self._opt_step("Vh", hp.lr_Vh)
+            # ---- policy (informarl.py:405-457)
+            act = self.policy.forward(feats, n_seq=Eb * C * n, T=hp.rnn_step, h0=None, tag="tr")
+            lp = self.arena.get("mb.lp", R)
+            ent = self.arena.get("mb.ent", R)
+            dms = self.arena.get("mb.dms", R, 4)
+            K.policy_head(act["ms"], self.eps_hat, ro.actions.index_select(0, idx).view(R, 2), None, lp, ent, n, 2,
+                          ro.log_pis.index_select(0, idx).view(R), tg["adv"].index_select(0, idx).view(R), dms,
+                          self.stats[2], hp.clip_eps, hp.coef_ent)
+            self.policy.zero_grads()
+            self.policy.backward(act, dms)
+            self._opt_step("policy", hp.lr_actor)
+        self._last = dict(Ql_mb=Ql_mb, G=G, R=R, nh=nh, B=B)
+        return self.info(ro)
+
+    def info(self, ro: RolloutData) -> dict:
+        """scalars of the LAST minibatch (dgppo.py:292) with the reference's key names; one host sync."""
+        L = self._last
+        s = self.stats.cpu().numpy()
+        G, R, nh, B = L["G"], L["R"], L["nh"], L["B"]
+        o = {k: self.opt[k].state.cpu().numpy() for k in self.opt}
+        pol_loss = s[2, 0] / R - self.hp.coef_ent * s[2, 1] / R
+        return {
+            "Vl/loss": float(s[0, 0] / G), "Vl/grad_norm": float(o["Vl"][4]), "Vl/has_nan": float(o["Vl"][5]),
+            "Vl/max_target": float(L["Ql_mb"].max()), "Vl/min_target": float(L["Ql_mb"].min()),
+            "Vh/loss_Vh": float(s[1, 0] / (R * nh)), "Vh/grad_Vh_norm": float(o["Vh"][4]),
+            "Vh/grad_Vh_has_nan": float(o["Vh"][5]),
+            "policy/loss": float(pol_loss), "policy/grad_norm": float(o["policy"][4]), "policy/has_nan": float(o["policy"][5]),
+            "policy/log_pi_min": float(ro.log_pis.min()), "policy/clip_frac": float(s[2, 2] / R),
+            "policy/entropy": float(s[2, 1] / R), "policy/total_variation_dist": float(0.5 * s[2, 3] / R),
+            "eval/safe_data": float(s[3, 0] / (B * self.T * self.cfg.n_agents)),
+        }

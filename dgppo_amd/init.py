@@ -1,0 +1,77 @@
+"""Host-side parameter initialisation (construction time only, not on the hot path): the distributions the reference
+uses — flax orthogonal(scale) Dense kernels, zero biases, LayerNorm (1, 0), GRUCell lecun-normal input kernels and
+orthogonal recurrent kernels (dgppo/nn/utils.py:20-27).  JAX's PRNG stream cannot be reproduced, so the
+values differ from a JAX run with the same seed; the distributions do not."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def orthogonal(rng: np.random.Generator, n_in: int, n_out: int, scale: float = 1.0) -> np.ndarray:
+    a = rng.standard_normal((max(n_in, n_out), min(n_in, n_out)))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diagonal(r))
+    if n_in < n_out:
+        q = q.T
+    return (scale * q).astype(np.float32)
+
+
+def lecun_normal(rng: np.random.Generator, n_in: int, n_out: int) -> np.ndarray:
+    std = math.sqrt(1.0 / n_in) / 0.87962566103423978
+    x = rng.standard_normal((n_in, n_out))
+    bad = np.abs(x) > 2.0
+    while bad.any():                      # truncated normal on [-2, 2]
+        x[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (x * std).astype(np.float32)
+
+
+def _dense(rng, n_in, n_out, bias=True, scale=1.0):
+    p = {"kernel": orthogonal(rng, n_in, n_out, scale)}
+    if bias:
+        p["bias"] = np.zeros(n_out, np.float32)
+    return p
+
+
+def _gnn(rng, node_dim, n_layers, msg_dim=32, out_dim=64, n_heads=3):
+    p, f = {}, node_dim
+    for i in range(n_layers):
+        d = out_dim if i == n_layers - 1 else msg_dim
+        hd = d * n_heads
+        p[f"GraphTransformer_{i}"] = {"Dense_0": _dense(rng, f, hd), "Dense_1": _dense(rng, f, hd), "Dense_2": _dense(rng, f, hd),
+                                      "Dense_3": _dense(rng, 4, hd, bias=False), "Dense_4": _dense(rng, f, d)}
+        f = d
+    return p
+
+
+def _mlp(rng):
+    p = {}
+    for i in range(2):
+        p[f"Dense_{i}"] = _dense(rng, 64, 64)
+        p[f"LayerNorm_{i}"] = {"scale": np.ones(64, np.float32), "bias": np.zeros(64, np.float32)}
+    return p
+
+
+def _gru(rng):
+    z = lambda: np.zeros(64, np.float32)
+    return {"ir": {"kernel": lecun_normal(rng, 64, 64), "bias": z()}, "iz": {"kernel": lecun_normal(rng, 64, 64), "bias": z()},
+            "in": {"kernel": lecun_normal(rng, 64, 64), "bias": z()}, "hr": {"kernel": orthogonal(rng, 64, 64)},
+            "hz": {"kernel": orthogonal(rng, 64, 64)}, "hn": {"kernel": orthogonal(rng, 64, 64), "bias": z()}}
+
+
+def init_policy(seed: int, node_dim: int, action_dim: int, gnn_layers: int) -> dict:
+    rng = np.random.default_rng([seed, 1])
+    return {"params": {
+        "PolicyNet_0": {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "PolicyGNNHead": _mlp(rng),
+                        "RNN_0": {"GRUCell_1": _gru(rng)}},
+        "ScaleHid": _dense(rng, 64, 64, scale=0.01),
+        "OutputDenseMean": _dense(rng, 64, action_dim),
+        "OutputDenseStdTrans": _dense(rng, 64, action_dim)}}
+
+
+def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, stream: int) -> dict:
+    rng = np.random.default_rng([seed, stream])
+    return {"params": {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "ValueGNNHead": _mlp(rng),
+                       "RNN_0": {"GRUCell_1": _gru(rng)}, "Dense_0": _dense(rng, 64, n_out)}}

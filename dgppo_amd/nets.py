@@ -164,7 +164,8 @@ class Net:
         self.prep_grads.zero_()
 
     # ---- forward ---------------------------------------------------------------------------------------------------
-    def forward(self, feats: GraphFeats, n_seq: int, T: int, h0: Optional[torch.Tensor], tag: str = "f"):
+    def forward(self, feats: GraphFeats, n_seq: int, T: int, h0: Optional[torch.Tensor], tag: str = "f",
+                hs_out: Optional[torch.Tensor] = None, train: bool = True):
         """Trunk + GRU + output Dense(s).  Graphs are ordered (group, time): G = (n_seq / n_inner) * T.
         Returns a dict of activations (views into this net's arena, valid until the next forward with the same tag)."""
         cfg, G, A = self.cfg, feats.G, self.arena
@@ -206,9 +207,9 @@ class Net:
             x = y
         gi = A.get(f"{tag}.gi", Rh, 3 * HID)
         K.dense_fwd(x, self.p("gru.Wi"), self.p("gru.bi"), gi)
-        hs = A.get(f"{tag}.hs", Rh, HID)
-        hprev = A.get(f"{tag}.hprev", Rh, HID)
-        gates = A.get(f"{tag}.gates", Rh, 4 * HID)
+        hs = hs_out if hs_out is not None else A.get(f"{tag}.hs", Rh, HID)
+        hprev = A.get(f"{tag}.hprev", Rh, HID) if train else None
+        gates = A.get(f"{tag}.gates", Rh, 4 * HID) if train else None
         assert n_seq * T == Rh, (n_seq, T, Rh)
         K.gru_fwd(gi, self.p("gru.Wh"), self.p("gru.bhn"), h0, hs, hprev, gates, n_seq, T, n_inner)
         act["gi"], act["hs"], act["hprev"], act["gates"] = gi, hs, hprev, gates

@@ -1,0 +1,124 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path (dgppo_amd/).
+
+Torch-CPU restatement of DGPPO.update_inner for ONE minibatch (dgppo/algo/dgppo.py:188-294, informarl.py:357-457,
+dgppo.py:296-321) on top of oracle/nn_torch.py (per-edge networks), oracle/env_np.py (graphs) and oracle/algo_ref.py (GAE).
+PARITY UNPINNED w.r.t. the reference's own outputs; it pins the HIP engine's orchestration: carry conventions
+(SURVEY A.8), chunking with zero initial carry, minibatch indexing, loss definitions and gradients.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import algo_ref as A
+from . import env_np as E
+from . import nn_torch as T
+
+
+def graphs_of(ocfg, agent, goal, obst, hits):
+    """agent [B,T1,n,sd], hits [B,T1,n,k,2] -> torch graph dict with leading axes [B,T1]."""
+    B, T1 = agent.shape[:2]
+    flat = lambda x: None if x is None else x.reshape((B * T1,) + x.shape[2:])
+    rep = lambda x: None if x is None else np.repeat(x, T1, axis=0)
+    g = E.get_graph(ocfg, flat(agent), rep(goal), rep(obst), flat(hits))
+    return {k: torch.from_numpy(v).view((B, T1) + v.shape[1:]) for k, v in g.items()}
+
+
+def _sel(g, b=None, t=None):
+    out = {}
+    for k, v in g.items():
+        x = v
+        if b is not None:
+            x = x[b]
+        if t is not None:
+            x = x[:, t]
+        out[k] = x
+    return out
+
+
+def values(trees, ocfg, ro, stochastic):
+    """-> Vl [B,T+1] (stochastic only), Vh [B,T+1,n,nh].  ro: dict of numpy arrays (env-major)."""
+    n = ocfg.n_agents
+    g = graphs_of(ocfg, ro["agent"], ro["goal"], ro["obst"], ro["hits"])
+    B, T1 = ro["agent"].shape[:2]
+    Tn = T1 - 1
+    rnn = torch.from_numpy(ro["rnn_states"])                     # [B,T,n,64] stored carry
+    with torch.no_grad():
+        Vl = None
+        if stochastic:
+            h = torch.zeros(B, 1, 64)
+            vs = []
+            for t in range(T1):                                  # scan_Vl + final value on next_graph[-1] (dgppo.py:204-216)
+                v, h = T.value_Vl(trees["Vl"], _sel(g, t=t), h, n)
+                vs.append(v)
+            Vl = torch.stack(vs, 1).numpy()
+        flat = {k: v[:, :Tn].reshape((B * Tn,) + v.shape[2:]) for k, v in g.items()}
+        Vh, _ = T.value_Vh(trees["Vh"], flat, rnn.reshape(B * Tn, n, 64), n)          # dgppo.py:219-220
+        Vh = Vh.view(B, Tn, n, -1)
+        _, hstar = T.policy_net(trees["policy"], _sel(g, t=Tn), rnn[:, -1], n)        # dgppo.py:222-226
+        Vh_fin, _ = T.value_Vh(trees["Vh"], _sel(g, t=Tn), hstar, n)
+        Vh = torch.cat([Vh, Vh_fin[:, None]], 1).numpy()
+    return Vl, Vh
+
+
+def targets(trees, ocfg, ro, det, hp, cbf_weight):
+    Vl, Vh = values(trees, ocfg, ro, True)
+    _, Vh_det = values(trees, ocfg, det, False)
+    Qh, Ql = A.gae_batch(ro["costs"], ro["rewards"], Vh, Vl, hp["gamma"], hp["gae_lambda"])
+    Qh_det, _ = A.gae_batch(det["costs"], det["rewards"], Vh_det, Vl, hp["gamma"], hp["gae_lambda"])
+    adv, safe = A.advantage(Ql, Vl, Vh, ocfg.dt, hp["alpha"], hp["cbf_eps"], cbf_weight)
+    return dict(Vl=Vl, Vh=Vh, Vh_det=Vh_det, Ql=Ql, Qh=Qh, Qh_det=Qh_det, adv=adv, safe=safe)
+
+
+def minibatch_losses(trees, ocfg, ro, det, tg, idx, hp, eps_hat):
+    """losses + autograd gradients of the three networks for the minibatch `idx` (env indices).
+    trees must have requires_grad leaves."""
+    n = ocfg.n_agents
+    rs = hp["rnn_step"]
+    B, T1 = ro["agent"].shape[:2]
+    Tn = T1 - 1
+    C = Tn // rs
+    sub = lambda d, k: None if d[k] is None else d[k][idx]
+    g = graphs_of(ocfg, ro["agent"][idx][:, :Tn], sub(ro, "goal"), sub(ro, "obst"),
+                  None if ro["hits"] is None else ro["hits"][idx][:, :Tn])
+    Eb = len(idx)
+    chunk = lambda v: v.reshape((Eb * C, rs) + v.shape[2:])       # (env, chunk) groups, zero initial carry
+    gc = {k: chunk(v) for k, v in g.items()}
+    out = {}
+    # ---- Vl
+    h = torch.zeros(Eb * C, 1, 64)
+    vs = []
+    for tau in range(rs):
+        v, h = T.value_Vl(trees["Vl"], _sel(gc, t=tau), h, n)
+        vs.append(v)
+    v_pred = torch.stack(vs, 1).reshape(Eb, Tn)
+    loss_Vl = (0.5 * (v_pred - torch.from_numpy(tg["Ql"][idx])) ** 2).mean()
+    loss_Vl.backward()
+    out["Vl/loss"] = float(loss_Vl.detach())
+    # ---- Vh on the deterministic rollout with ITS stored carry
+    gd = graphs_of(ocfg, det["agent"][idx][:, :Tn], sub(det, "goal"), sub(det, "obst"),
+                   None if det["hits"] is None else det["hits"][idx][:, :Tn])
+    flat = {k: v.reshape((Eb * Tn,) + v.shape[2:]) for k, v in gd.items()}
+    vh, _ = T.value_Vh(trees["Vh"], flat, torch.from_numpy(det["rnn_states"][idx]).reshape(Eb * Tn, n, 64), n)
+    loss_Vh = (0.5 * (vh.view(Eb, Tn, n, -1) - torch.from_numpy(tg["Qh_det"][idx])) ** 2).mean()
+    loss_Vh.backward()
+    out["Vh/loss_Vh"] = float(loss_Vh.detach())
+    # ---- policy
+    a_in = chunk(torch.from_numpy(ro["actions"][idx]))
+    h = torch.zeros(Eb * C, n, 64)
+    lps, ents = [], []
+    for tau in range(rs):
+        lp, ent, h = T.policy_eval(trees["policy"], _sel(gc, t=tau), a_in[:, tau], h, n, eps_hat)
+        lps.append(lp); ents.append(ent)
+    lp = torch.stack(lps, 1).reshape(Eb, Tn, n)
+    ent = torch.stack(ents, 1).reshape(Eb, Tn, n)
+    rho = torch.exp(lp - torch.from_numpy(ro["log_pis"][idx]))
+    Aadv = torch.from_numpy(tg["adv"][idx])
+    l1 = -rho * Aadv
+    l2 = -torch.clamp(rho, 1 - hp["clip_eps"], 1 + hp["clip_eps"]) * Aadv
+    loss_pol = torch.maximum(l1, l2).mean() - hp["coef_ent"] * ent.mean()
+    loss_pol.backward()
+    out.update({"policy/loss": float(loss_pol.detach()), "policy/clip_frac": float((l2 > l1).float().mean()),
+                "policy/entropy": float(ent.mean().detach()), "policy/total_variation_dist": float(0.5 * (rho - 1).abs().mean().detach())})
+    return out
