@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Benchmark of the DGPPO hot path on MI355X.
+
+One "step" = one full DGPPO training iteration on the workload of BASELINE.json (LidarSpread, n=8 agents, 3 obstacles,
+4096 envs per GPU, T=128): stochastic rollout (collect) + deterministic rollout + value pre-passes + 2x GAE + advantage +
+all PPO minibatch updates (Vl, Vh, policy; clip + Adam), i.e. exactly what `algo.collect` + `algo.update` do per
+iteration (dgppo/trainer/trainer.py:131-137).  Counted work = B*T env-steps of the stochastic rollout per iteration
+(BASELINE.md §3).  Synthetic random scenes, random-init networks.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (raycast+graph kernel vs the HBM roofline, timed with HIP events
+inside this process), "cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample), "phases".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--env", type=str, default="LidarSpread")
+    p.add_argument("-n", "--num-agents", type=int, default=8)
+    p.add_argument("--obs", type=int, default=3)
+    p.add_argument("--n-env", type=int, default=4096, help="envs PER GPU (weak scaling)")
+    p.add_argument("--batch-size", type=int, default=16384)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    return p.parse_args()
+
+
+def roofline_env_kernel(cfg, device, B, iters=50):
+    """Raycast+graph kernel (dgppo_env_step with the materialised GraphsTuple) alone, timed with HIP events on the stream it
+    is launched on.  Algorithmic bytes per env-step: SURVEY §8(d) B_api (+ the pre-step hit points the cost reads)."""
+    from dgppo_amd import ops_env as OE
+    n, sd, k = cfg.n_agents, cfg.state_dim, cfg.top_k
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=device) * 2654435761
+    agent = torch.empty(B, n, sd, device=device); goal = torch.empty(B, n, sd, device=device)
+    obst = torch.empty(B, cfg.n_obs, cfg.obst_stride, device=device)
+    OE.env_reset(cfg, seeds, agent, goal, obst)
+    rc, rs = OE.ray_tables(cfg.n_rays, device)
+    hits = torch.empty(B, n, k, 2, device=device)
+    OE.env_step(cfg, agent, None, goal, obst, None, rc, rs, None, hits, None, None, None)
+    action = torch.empty(B, n, 2, device=device).uniform_(-1, 1)
+    nx = torch.empty_like(agent); nh = torch.empty_like(hits)
+    rew = torch.empty(B, device=device); cost = torch.empty(B, n, 2, device=device)
+    g = OE.alloc_graph(cfg, B, device)
+    N_, E_ = cfg.num_nodes, cfg.num_edges
+    obs_bytes = 4 * 13 * cfg.n_obs
+    R_ = 4 * (n * sd + 2 * n + n * sd) + obs_bytes
+    W_api = 4 * (N_ * cfg.node_dim + 4 * E_ + N_ * sd + 2 * E_ + N_) + 8 + 4 + 4 * n * 2
+    B_api = R_ + W_api                                                    # 9048 for LidarSpread n=8
+    W_min = 4 * (n * sd + 2 * n * k + 1 + n * 2) + (n * (n + k) + 7) // 8
+    B_min = R_ + W_min
+    out = {}
+    for name, graph, bytes_per in (("api", g, B_api), ("compact", None, B_min)):
+        for _ in range(5):
+            OE.env_step(cfg, agent, action, goal, obst, hits, rc, rs, nx, nh, rew, cost, graph)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            OE.env_step(cfg, agent, action, goal, obst, hits, rc, rs, nx, nh, rew, cost, graph)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out[name] = dict(us_per_launch=us, bytes_per_env_step=bytes_per, gbs=bytes_per * B / us / 1e3,
+                         env_steps_per_s=B / us * 1e6)
+    return out
+
+
+def cpu_baseline(seconds_budget: float):
+    """CPU restatement (JAX not installable offline): the oracle's full DGPPO iteration on a bounded sample."""
+    from oracle import train_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    B, T = 8, 128
+    t0 = time.time()
+    r = train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=B * T // 2, seed=0)
+    dt = time.time() - t0
+    iters = 1
+    while dt < seconds_budget * 0.5 and iters < 4:
+        t1 = time.time()
+        train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=B * T // 2, seed=iters)
+        dt += time.time() - t1
+        iters += 1
+    return {"value": B * T * iters / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} full DGPPO iteration(s) of the CPU oracle (numpy env + torch-CPU per-edge networks + autograd), "
+                      f"LidarSpread n=8 obs=3, {B} envs x {T} steps, batch {B * T // 2}; {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    allreduce = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+        def allreduce(t):
+            dist.all_reduce(t)
+            t.div_(world)
+
+    from dgppo_amd import _native as N, engine as EN, init
+
+    cfg = N.make_env_cfg(N.ENV_KINDS[args.env], args.num_agents, args.obs)
+    T = 128
+    hp = EN.Hyper(batch_size=args.batch_size, train_steps=1000)
+    eng = EN.Engine(cfg, hp, device, T=T, allreduce=allreduce)
+    eng.policy.load_tree(init.init_policy(0, cfg.node_dim, 2, hp.actor_gnn_layers))
+    eng.Vl.load_tree(init.init_value(0, cfg.node_dim, 1, hp.Vl_gnn_layers, 2))
+    eng.Vh.load_tree(init.init_value(0, cfg.node_dim, 2, hp.Vh_gnn_layers, 3))
+    eng.set_entropy_noise(12345)
+    B = args.n_env
+    rng = np.random.default_rng(1000 + rank)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    phases = {"collect": 0.0, "det_rollout": 0.0, "update": 0.0}
+
+    def iteration(it: int, timed: bool):
+        base = (np.arange(B, dtype=np.uint64) + np.uint64(rank * B + 1)) * np.uint64(0x9E3779B97F4A7C15)
+        seeds = torch.from_numpy((base ^ np.uint64(it * 7919 + 1)).view(np.int64)).to(device)
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        ro = eng.rollout(seeds, True, noise_seed=it * 2 + 1)                  # algo.collect
+        e[1].record()
+        det = eng.rollout(seeds ^ 0x5DEECE66D, False)                         # det_rollout_fn inside algo.update
+        e[2].record()
+        info = eng.update(ro, det, it, rng.permutation(B))                    # rest of algo.update (+ info sync)
+        e[3].record()
+        if timed:
+            torch.cuda.synchronize()
+            phases["collect"] += e[0].elapsed_time(e[1])
+            phases["det_rollout"] += e[1].elapsed_time(e[2])
+            phases["update"] += e[2].elapsed_time(e[3])
+        return info
+
+    for w in range(args.warmup):
+        iteration(w, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = None
+    for k in range(args.steps):
+        info = iteration(args.warmup + k, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    ms_per_step = dt * 1e3 / args.steps
+    value = world * B * T * args.steps / dt
+    rl = roofline_env_kernel(cfg, device, B) if cfg.is_lidar and cfg.n_obs > 0 else None
+    out = {
+        "metric": "env-steps/sec whole node, LidarSpread n=8 4096 envs, 1/2/4/8 GPUs",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.env} n={args.num_agents} obs={args.obs}, {B} envs/GPU x T=128, full DGPPO iteration "
+                               f"(collect + det rollout + value pre-passes + GAE + {B // (args.batch_size // T)} minibatches "
+                               f"of batch_size {args.batch_size}, rnn_step 16)",
+                   "envs_per_gpu": B, "global_envs": world * B, "parallelism": f"dp{world}"},
+        "phases_ms_per_step": {k: v / args.steps for k, v in phases.items()},
+        "rollout_only_env_steps_per_s": world * B * T / (phases["collect"] / args.steps / 1e3) if phases["collect"] else None,
+        "last_info": {k: info[k] for k in ("policy/loss", "Vl/loss", "Vh/loss_Vh", "eval/safe_data")},
+    }
+    if rl is not None:
+        out["roofline"] = {"bound": "hbm", "kernel": "env_step_kernel (dynamics + raycast + top-k + reward/cost + GraphsTuple emit)",
+                           "achieved": rl["api"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rl["api"]["gbs"] / HBM_PEAK_GBS,
+                           "traffic": None, "bytes_per_env_step": rl["api"]["bytes_per_env_step"],
+                           "us_per_launch": rl["api"]["us_per_launch"], "kernel_env_steps_per_s": rl["api"]["env_steps_per_s"],
+                           "compact": rl["compact"]}
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        except Exception as ex:  # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"error": repr(ex)}
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

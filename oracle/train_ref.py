@@ -1,0 +1,118 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path (dgppo_amd/).
+
+A complete DGPPO training iteration on the CPU assembled from the oracle pieces (numpy env, torch per-edge networks,
+autograd, numpy GAE/Adam): rollout (dgppo/trainer/utils.py:22-57), deterministic rollout (:60-86), update
+(dgppo/algo/dgppo.py:136-294).  Used (a) as bench.py's `cpu_baseline` ("port": JAX is not installable offline)
+and (b) for BASELINE config 1 (MPETarget n=3, 32 envs: plumbing on the CPU path).  PARITY UNPINNED (see the other oracle
+files).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import algo_ref as A
+from . import dgppo_ref as R
+from . import env_np as E
+from . import nn_torch as T
+
+HP = dict(gamma=0.99, gae_lambda=0.95, alpha=10.0, cbf_eps=1e-2, rnn_step=16, clip_eps=0.25, coef_ent=1e-2)
+LR = {"policy": 3e-4, "Vl": 1e-3, "Vh": 1e-3}
+
+
+def init_trees(ocfg, seed=0):
+    return {"policy": T.init_policy(seed, ocfg.node_dim), "Vl": T.init_value(seed + 1, ocfg.node_dim, 1, 2),
+            "Vh": T.init_value(seed + 2, ocfg.node_dim, 2, 1)}
+
+
+def rollout(ocfg, trees, seeds, T_steps, stochastic, rng: np.random.Generator):
+    n = ocfg.n_agents
+    agent, goal, obst = E.env_reset(ocfg, seeds)
+    tab = E.ray_table(ocfg.n_rays) if ocfg.is_lidar else None
+    has_hits = ocfg.is_lidar and ocfg.n_obs > 0
+    hits = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)[0] if has_hits else None
+    B = agent.shape[0]
+    h = torch.zeros(B, n, 64)
+    rec = {k: [] for k in ("agent", "hits", "actions", "log_pis", "rnn", "rewards", "costs")}
+    for t in range(T_steps):
+        g = T.graph_to_torch(E.get_graph(ocfg, agent, goal, obst if not ocfg.is_lidar else obst, hits))
+        with torch.no_grad():
+            if stochastic:
+                eps = torch.from_numpy(rng.standard_normal((B, n, 2)).astype(np.float32))
+                a, lp, h_new = T.policy_sample(trees["policy"], g, h, n, eps)
+                rec["log_pis"].append(lp.numpy())
+            else:
+                a, h_new = T.policy_mode(trees["policy"], g, h, n)
+        rec["agent"].append(agent); rec["hits"].append(hits); rec["actions"].append(a.numpy())
+        rec["rnn"].append((h if stochastic else h_new).numpy())
+        out = E.env_step(ocfg, agent, goal, obst, hits, a.numpy(), tab, want_graph=False)
+        rec["rewards"].append(out["reward"]); rec["costs"].append(out["cost"])
+        agent, hits, h = out["next_agent"], out["next_hits"], h_new
+    rec["agent"].append(agent); rec["hits"].append(hits)
+    st = lambda xs: np.stack(xs, 1)
+    return dict(agent=st(rec["agent"]), hits=st(rec["hits"]) if has_hits else None, goal=goal,
+                obst=obst if (obst is not None and obst.shape[1] > 0) else None, actions=st(rec["actions"]),
+                log_pis=st(rec["log_pis"]) if stochastic else None, rnn_states=st(rec["rnn"]), rewards=st(rec["rewards"]),
+                costs=st(rec["costs"]))
+
+
+class OptStates:
+    def __init__(self, trees):
+        self.s = {}
+        for k, tr in trees.items():
+            n = sum(v.numel() for _, v in T.tree_leaves(tr))
+            self.s[k] = [np.zeros(n), np.zeros(n), 0]
+
+
+def _apply(tree, name, opt: OptStates):
+    leaves = T.tree_leaves(tree)
+    p = np.concatenate([v.detach().numpy().ravel() for _, v in leaves]).astype(np.float64)
+    g = np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).numpy().ravel() for _, v in leaves])
+    m, v_, c = opt.s[name]
+    p, m, v_, c, norm, bad = A.clip_adam(p, g, m, v_, c, LR[name], 2.0)
+    opt.s[name] = [m, v_, c]
+    o = 0
+    for _, leaf in leaves:
+        k = leaf.numel()
+        leaf.data.copy_(torch.from_numpy(p[o:o + k].astype(np.float32)).view(leaf.shape))
+        leaf.grad = None
+        o += k
+    return norm, bad
+
+
+def update(ocfg, trees, opt, ro, det, step, train_steps, batch_size, perm, eps_hat, hp=HP):
+    w = A.cbf_weight_schedule(1.0, step, train_steps)
+    with torch.no_grad():
+        tg = R.targets(trees, ocfg, ro, det, hp, w)
+    B, T1 = ro["agent"].shape[:2]
+    Eb = batch_size // (T1 - 1)
+    info = {}
+    for mb in range(B // Eb):
+        for tr in trees.values():
+            for _, leaf in T.tree_leaves(tr):
+                leaf.requires_grad_(True)
+        idx = perm[mb * Eb:(mb + 1) * Eb]
+        info = R.minibatch_losses(trees, ocfg, ro, det, tg, idx, hp, eps_hat)
+        for name in ("Vl", "Vh", "policy"):
+            info[f"{name}/grad_norm"], _ = _apply(trees[name], name, opt)
+        for tr in trees.values():
+            for _, leaf in T.tree_leaves(tr):
+                leaf.requires_grad_(False)
+    info["eval/safe_data"] = tg["safe"]
+    return info
+
+
+def iteration(kind_name, n, n_obs, B, T, batch_size, seed=0, state=None, step=0, train_steps=1000):
+    ocfg = E.EnvCfg(E.KIND_NAMES[kind_name], n_agents=n, n_obs=n_obs)
+    rng = np.random.default_rng(seed)
+    if state is None:
+        trees = init_trees(ocfg, seed)
+        state = dict(trees=trees, opt=OptStates(trees),
+                     eps_hat=torch.from_numpy(rng.standard_normal((n, 2)).astype(np.float32)))
+    seeds = rng.integers(1, 2 ** 62, size=B)
+    ro = rollout(ocfg, state["trees"], seeds, T, True, rng)
+    det = rollout(ocfg, state["trees"], rng.integers(1, 2 ** 62, size=B), T, False, rng)
+    info = update(ocfg, state["trees"], state["opt"], ro, det, step, train_steps, batch_size, rng.permutation(B), state["eps_hat"])
+    info["reward_mean"] = float(ro["rewards"].sum(1).mean())
+    return state, info
