@@ -27,6 +27,24 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def log(msg):
+    """progress to stderr (and gpurun_out/ when present) so a long run never looks hung."""
+    line = f"[bench {time.strftime('%H:%M:%S')}] {msg}"
+    print(line, file=sys.stderr, flush=True)
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "bench_progress.log"), "a") as f:
+            f.write(line + "\n")
+
+
+def host_threads():
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    return max(1, min(16, aff))
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -84,11 +102,12 @@ def roofline_env_kernel(cfg, device, B, iters=50):
 def cpu_baseline(seconds_budget: float):
     """CPU restatement (JAX not installable offline): the oracle's full DGPPO iteration on a bounded sample."""
     from oracle import train_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     B, T = 8, 128
     t0 = time.time()
     r = train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=B * T // 2, seed=0)
     dt = time.time() - t0
+    log(f"cpu_baseline: first oracle iteration took {dt:.1f} s on {torch.get_num_threads()} threads")
     iters = 1
     while dt < seconds_budget * 0.5 and iters < 4:
         t1 = time.time()
@@ -139,8 +158,12 @@ def main():
         e[0].record()
         ro = eng.rollout(seeds, True, noise_seed=it * 2 + 1)                  # algo.collect
         e[1].record()
+        if it == 0:
+            torch.cuda.synchronize(); log("first collect done")
         det = eng.rollout(seeds ^ 0x5DEECE66D, False)                         # det_rollout_fn inside algo.update
         e[2].record()
+        if it == 0:
+            torch.cuda.synchronize(); log("first det rollout done")
         info = eng.update(ro, det, it, rng.permutation(B))                    # rest of algo.update (+ info sync)
         e[3].record()
         if timed:
@@ -150,8 +173,11 @@ def main():
             phases["update"] += e[2].elapsed_time(e[3])
         return info
 
+    log(f"rank {rank}/{world}: engine ready, B={B} envs, starting {args.warmup} warm-up iteration(s)")
     for w in range(args.warmup):
         iteration(w, False)
+        torch.cuda.synchronize()
+        log(f"warm-up {w} done")
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -160,6 +186,7 @@ def main():
     info = None
     for k in range(args.steps):
         info = iteration(args.warmup + k, True)
+        log(f"timed iteration {k} done ({time.perf_counter() - t0:.2f} s since start)")
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -175,7 +202,9 @@ def main():
         return
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * T * args.steps / dt
+    log(f"training timed: {ms_per_step:.1f} ms/iteration -> {value:.0f} env-steps/s; timing the raycast+graph kernel")
     rl = roofline_env_kernel(cfg, device, B) if cfg.is_lidar and cfg.n_obs > 0 else None
+    log(f"roofline kernel: {rl}")
     out = {
         "metric": "env-steps/sec whole node, LidarSpread n=8 4096 envs, 1/2/4/8 GPUs",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
