@@ -109,7 +109,7 @@ def cpu_baseline(seconds_budget: float):
     dt = time.time() - t0
     log(f"cpu_baseline: first oracle iteration took {dt:.1f} s on {torch.get_num_threads()} threads")
     iters = 1
-    while dt < seconds_budget * 0.5 and iters < 4:
+    while dt < seconds_budget * 0.75 and iters < 12:
         t1 = time.time()
         train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=B * T // 2, seed=iters)
         dt += time.time() - t1
@@ -127,16 +127,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    allreduce = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
-
-        def allreduce(t):
-            dist.all_reduce(t)
-            t.div_(world)
-
-    from dgppo_amd import _native as N, engine as EN, init
+    from dgppo_amd import _native as N, engine as EN, init, dist as D
+    D.init(backend="nccl", device=device)
+    allreduce = D.make_allreduce(world)          # RCCL all-reduce of each net's flat gradient buffer per minibatch step
 
     cfg = N.make_env_cfg(N.ENV_KINDS[args.env], args.num_agents, args.obs)
     T = 128
@@ -152,8 +145,7 @@ def main():
     phases = {"collect": 0.0, "det_rollout": 0.0, "update": 0.0}
 
     def iteration(it: int, timed: bool):
-        base = (np.arange(B, dtype=np.uint64) + np.uint64(rank * B + 1)) * np.uint64(0x9E3779B97F4A7C15)
-        seeds = torch.from_numpy((base ^ np.uint64(it * 7919 + 1)).view(np.int64)).to(device)
+        seeds = torch.from_numpy(D.shard_seeds(rank, B, it)).to(device)
         e = [ev() for _ in range(4)]
         e[0].record()
         ro = eng.rollout(seeds, True, noise_seed=it * 2 + 1)                  # algo.collect
@@ -192,10 +184,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = D.max_over_ranks(dt, world, device)
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()

@@ -1,0 +1,12 @@
+"""dgppo.algo equivalent (dgppo/algo/__init__.py:8-18)."""
+from .base import Algorithm
+from .dgppo import DGPPO
+
+
+def make_algo(algo: str, **kwargs) -> Algorithm:
+    if algo == "dgppo":
+        return DGPPO(**kwargs)
+    if algo in ("informarl", "informarl_lagr", "hcbfcrpo"):
+        raise NotImplementedError(f"algo '{algo}' is a baseline of the reference outside the hot-path scope of this build "
+                                  f"(SURVEY §2 rows 18-19, §8f rank 3); available: 'dgppo'")
+    raise ValueError(f"Unknown algorithm: {algo}")

@@ -1,0 +1,198 @@
+"""DGPPO with the reference's constructor / method surface (dgppo/algo/dgppo.py:27-321 through
+informarl_lagr.py:27-123 and informarl.py:30-256), driving the HIP engine.
+
+Differences that cannot be avoided and are recorded in DESIGN.md: PRNG keys are integer seeds (JAX threefry streams are not
+reproducible); `params` are flax-named trees of numpy arrays snapshotted from the device buffers."""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import engine as EN
+from .. import init as INIT
+from .. import nets
+from .. import ops_nn as K
+from ..trainer.data import Rollout
+from ..utils.graph import GraphsTuple
+from .base import Algorithm
+
+
+class _LazyGraphs:
+    """rollout.graph / rollout.next_graph: GraphsTuple fields of all (env, t), materialised on first access."""
+
+    def __init__(self, env, ro: EN.RolloutData, offset: int):
+        self._env, self._ro, self._off, self._g = env, ro, offset, None
+
+    def _mat(self):
+        if self._g is None:
+            ro, T, off = self._ro.finalize(), self._ro.T, self._off
+            B = ro.B
+            flat = lambda x: None if x is None else x[:, off:off + T].reshape((B * T,) + x.shape[2:]).contiguous()
+            rep = lambda x: None if x is None else x.repeat_interleave(T, dim=0)
+            from ..env.base import BatchState
+            g = self._env.graph_batch(BatchState(flat(ro.agent), rep(ro.goal), rep(ro.obst), flat(ro.hits)))
+            unf = lambda x: x.view((B, T) + x.shape[1:]) if torch.is_tensor(x) else x
+            es = g.env_states
+            es = type(es)(*[_unflatten_tree(v, B, T) for v in es])
+            self._g = GraphsTuple(*[unf(getattr(g, f)) for f in GraphsTuple._fields[:8]], es, None)
+        return self._g
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._mat(), name)
+
+    def _replace(self, **kw):
+        return self._mat()._replace(**kw)
+
+
+def _unflatten_tree(v, B, T):
+    if torch.is_tensor(v):
+        return v.view((B, T) + v.shape[1:])
+    if isinstance(v, tuple) and hasattr(v, "_fields"):
+        return type(v)(*[_unflatten_tree(x, B, T) for x in v])
+    return v
+
+
+class DGPPO(Algorithm):
+    def __init__(self, env, node_dim: int, edge_dim: int, state_dim: int, action_dim: int, n_agents: int,
+                 actor_gnn_layers: int = 2, Vl_gnn_layers: int = 2, Vh_gnn_layers: int = 1, gamma: float = 0.99,
+                 lr_actor: float = 3e-4, lr_Vl: float = 1e-3, lr_Vh: float = 1e-3, batch_size: int = 8192,
+                 epoch_ppo: int = 1, clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2,
+                 max_grad_norm: float = 2.0, seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16,
+                 use_lstm: bool = False, alpha: float = 10.0, cbf_eps: float = 1e-2, cbf_weight: float = 1.0,
+                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, **kwargs):
+        super().__init__(env, node_dim, edge_dim, action_dim, n_agents)
+        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
+            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1 "
+                                      "(LSTM / no-rnn are next-tier, SURVEY §2 row 9)")
+        assert node_dim == env.node_dim and action_dim == 2
+        self.state_dim = state_dim
+        self.seed = seed
+        self.epoch_ppo, self.use_rnn, self.rnn_layers, self.use_lstm = epoch_ppo, use_rnn, rnn_layers, use_lstm
+        self.hp = EN.Hyper(gamma=gamma, gae_lambda=gae_lambda, clip_eps=clip_eps, coef_ent=coef_ent,
+                           max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
+                           rnn_step=rnn_step, alpha=alpha, cbf_eps=cbf_eps, cbf_weight=cbf_weight, cbf_schedule=cbf_schedule,
+                           train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers, Vl_gnn_layers=Vl_gnn_layers,
+                           Vh_gnn_layers=Vh_gnn_layers)
+        self.device = env.device
+        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce)
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
+        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3))
+        # np.random.randint(0, 102400) at trace time in the reference (distribution.py:40)
+        self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
+        # (n_rnn_layers, n_agents, n_carries, rnn_state_dim), zeros (informarl.py:115-124)
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self._rng = np.random.default_rng([seed, 99])
+        self._single = nets.Arena(self.device)
+
+    # ---- reference properties ----
+    @property
+    def config(self) -> dict:
+        hp = self.hp
+        return {"cost_weight": 0.0, "actor_gnn_layers": hp.actor_gnn_layers, "Vl_gnn_layers": hp.Vl_gnn_layers,
+                "gamma": hp.gamma, "lr_actor": hp.lr_actor, "lr_Vl": hp.lr_Vl, "batch_size": hp.batch_size,
+                "epoch_ppo": self.epoch_ppo, "clip_eps": hp.clip_eps, "gae_lambda": hp.gae_lambda, "coef_ent": hp.coef_ent,
+                "max_grad_norm": hp.max_grad_norm, "seed": self.seed, "use_rnn": self.use_rnn, "rnn_layers": self.rnn_layers,
+                "rnn_step": hp.rnn_step, "use_lstm": self.use_lstm, "cost_schedule": False, "lr_Vh": hp.lr_Vh,
+                "Vh_gnn_layers": hp.Vh_gnn_layers, "lagr_init": 0.78, "lr_lagr": 1e-7, "alpha": hp.alpha,
+                "cbf_eps": hp.cbf_eps, "cbf_weight": hp.cbf_weight, "cbf_schedule": hp.cbf_schedule}
+
+    @property
+    def params(self):
+        e = self.engine
+        return {"policy": e.policy.to_tree(), "Vl": e.Vl.to_tree(), "Vh": e.Vh.to_tree()}
+
+    def _maybe_load(self, params):
+        if params is not None:
+            for k, net in self.engine.nets.items():
+                if k in params:
+                    net.load_tree(params[k])
+
+    # ---- single-graph act / step (B = 1 view of the batched kernels) ----
+    def _policy_single(self, graph: GraphsTuple, rnn_state):
+        env, cfg = self._env, self._env.cfg
+        st = env._state_of(graph)
+        n = cfg.n_agents
+        feats = self.engine._feats_at("one", st.agent, st.hits, st.goal, st.obst, 1)
+        h0 = torch.as_tensor(rnn_state, dtype=torch.float32, device=self.device).reshape(n, nets.HID).contiguous()
+        hs = torch.empty(n, nets.HID, device=self.device)
+        act = self.engine.policy.forward(feats, n_seq=n, T=1, h0=h0, tag="one", hs_out=hs, train=False)
+        return act["ms"], hs.view(1, n, 1, nets.HID)
+
+    def act(self, graph: GraphsTuple, rnn_state, params=None):
+        self._maybe_load(params)
+        ms, new_rnn = self._policy_single(graph, rnn_state)
+        action = torch.empty(self.n_agents, 2, device=self.device)
+        K.policy_head(ms, None, None, action, None, None, self.n_agents, 1)
+        return action, new_rnn
+
+    def step(self, graph: GraphsTuple, rnn_state, key, params=None):
+        self._maybe_load(params)
+        ms, new_rnn = self._policy_single(graph, rnn_state)
+        from .. import ops_env as OE
+        eps = torch.empty(self.n_agents, 2, device=self.device)
+        OE.randn(int(key), 0, eps.view(-1))
+        action = torch.empty(self.n_agents, 2, device=self.device)
+        log_pi = torch.empty(self.n_agents, device=self.device)
+        K.policy_head(ms, eps, None, action, log_pi, None, self.n_agents, 0)
+        return action, log_pi, new_rnn
+
+    # ---- collect / update ----
+    def _seeds(self, keys) -> torch.Tensor:
+        if torch.is_tensor(keys):
+            return keys.to(self.device, torch.int64)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(keys).astype(np.uint64).view(np.int64))).to(self.device)
+
+    def _wrap(self, ro: EN.RolloutData, env=None) -> Rollout:
+        ro.finalize()
+        env = self._env if env is None else env
+        r = Rollout(_LazyGraphs(env, ro, 0), ro.actions, ro.rnn_states.unsqueeze(2).unsqueeze(4), ro.rewards, ro.costs,
+                    torch.zeros(ro.B, ro.T, dtype=torch.bool, device=self.device), ro.log_pis, _LazyGraphs(env, ro, 1))
+        self._last_rollouts = getattr(self, "_last_rollouts", {})
+        self._last_rollouts[id(r.actions)] = ro
+        return r
+
+    def collect(self, params, keys) -> Rollout:
+        """algo.collect(params, keys): one stochastic rollout per key (informarl.py:254-256)."""
+        self._maybe_load(params)
+        ro = self.engine.rollout(self._seeds(keys), True, noise_seed=int(self._rng.integers(1, 2 ** 62)))
+        return self._wrap(ro)
+
+    def collect_deterministic(self, keys, env=None) -> Rollout:
+        eng = self.engine
+        if env is not None and env is not self._env:
+            assert env.cfg.kind == self._env.cfg.kind and env.num_agents == self.n_agents
+        ro = eng.rollout(self._seeds(keys), False)
+        return self._wrap(ro, env)
+
+    def update(self, rollout: Rollout, step: int) -> dict:
+        ro = self._last_rollouts.pop(id(rollout.actions), None)
+        if ro is None:
+            raise ValueError("update() needs a Rollout produced by this algo's collect()")
+        self._last_rollouts.clear()
+        # deterministic rollout for the constraint-value targets (dgppo.py:139-141)
+        det = self.engine.rollout(self._seeds(self._rng.integers(1, 2 ** 62, size=ro.B)), False)
+        perm = np.arange(ro.B)
+        np.random.shuffle(perm)                              # host np.random like the reference (dgppo.py:155-156)
+        return self.engine.update(ro, det, int(step), perm)
+
+    # ---- checkpoints: {dir}/{step}/{actor,Vl,Vh}.pkl with flax-named params (informarl_lagr.py:311-327) ----
+    def save(self, save_dir: str, step: int):
+        model_dir = os.path.join(save_dir, str(step))
+        os.makedirs(model_dir, exist_ok=True)
+        p = self.params
+        for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl"), ("Vh.pkl", "Vh")):
+            with open(os.path.join(model_dir, fname), "wb") as f:
+                pickle.dump(p[key], f)
+
+    def load(self, load_dir: str, step: int):
+        path = os.path.join(load_dir, str(step))
+        for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl"), ("Vh.pkl", "Vh")):
+            with open(os.path.join(path, fname), "rb") as f:   # files written by save() above (our own pickles)
+                self.engine.nets[key].load_tree(pickle.load(f))

@@ -1,0 +1,223 @@
+"""MultiAgentEnv with the reference's attribute / method surface (dgppo/env/base.py:30-150), backed by the batched HIP
+kernels.  The reference's single-graph methods (`reset(key)`, `step(graph, action)`) are the B = 1 view of the batched
+ones (`reset_batch`, `step_batch`) that the engine uses."""
+from __future__ import annotations
+
+from abc import ABC
+from typing import NamedTuple, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _native as N
+from .. import ops_env as OE
+from ..utils.graph import GraphsTuple
+
+
+class StepResult(NamedTuple):
+    graph: GraphsTuple
+    reward: torch.Tensor
+    cost: torch.Tensor
+    done: torch.Tensor
+    info: dict
+
+
+class BatchState(NamedTuple):
+    """compact batched env state (device tensors)."""
+    agent: torch.Tensor            # [B, n, sd]
+    goal: torch.Tensor             # [B, n, sd]
+    obst: Optional[torch.Tensor]   # LiDAR: [B, n_obs, 16] rectangle records; MPE: [B, n_obs, sd]
+    hits: Optional[torch.Tensor]   # LiDAR: [B, n, k, 2]
+
+
+class MultiAgentEnv(ABC):
+    PARAMS: dict = {}
+    KIND: str = ""
+
+    def __init__(self, num_agents: int, area_size: Optional[float] = None, max_step: int = 128, dt: float = 0.03,
+                 params: Optional[dict] = None, device: Optional[torch.device] = None):
+        self._params = dict(self.PARAMS) if params is None else params
+        self._num_agents = num_agents
+        self._area_size = self._params["default_area_size"] if area_size is None else area_size
+        self._dt = dt
+        self._max_step = max_step
+        self.num_goals = num_agents
+        self._device = device
+        p = self._params
+        self.cfg = N.make_env_cfg(N.ENV_KINDS[self.KIND], num_agents, p["n_obs"], p.get("n_rays", 32), p.get("top_k_rays", 8),
+                                  self._area_size, dt, p["car_radius"], p["comm_radius"], p.get("obs_radius", 0.05),
+                                  p["dist2goal"])
+        self._ray = None
+
+    # ---- reference attribute surface ----
+    @property
+    def params(self) -> dict:
+        return self._params
+
+    @property
+    def num_agents(self) -> int:
+        return self._num_agents
+
+    @property
+    def area_size(self) -> float:
+        return self._area_size
+
+    @property
+    def dt(self) -> float:
+        return self._dt
+
+    @property
+    def max_episode_steps(self) -> int:
+        return self._max_step
+
+    @property
+    def n_cost(self) -> int:
+        return 2
+
+    @property
+    def cost_components(self) -> Tuple[str, ...]:
+        return "agent collisions", "obs collisions"
+
+    @property
+    def state_dim(self) -> int:
+        return self.cfg.state_dim
+
+    @property
+    def node_dim(self) -> int:
+        return self.cfg.node_dim
+
+    @property
+    def edge_dim(self) -> int:
+        return 4
+
+    @property
+    def action_dim(self) -> int:
+        return 2
+
+    @property
+    def device(self) -> torch.device:
+        if self._device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("dgppo_amd environments run on the GPU only (no CPU fallback)")
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        return self._device
+
+    def state_lim(self, state=None):
+        a = self.area_size
+        if self.cfg.kind == 2:
+            return (torch.tensor([0., 0., -1., -1., -0.5]), torch.tensor([a, a, 1., 1., 0.5]))
+        v = 0.5 if self.cfg.is_lidar else 1.0
+        return torch.tensor([0., 0., -v, -v]), torch.tensor([a, a, v, v])
+
+    def action_lim(self):
+        return -torch.ones(2), torch.ones(2)
+
+    def clip_state(self, state):
+        lo, hi = self.state_lim()
+        return torch.minimum(torch.maximum(state, lo.to(state.device)), hi.to(state.device))
+
+    def clip_action(self, action):
+        return torch.clamp(action, -1.0, 1.0)
+
+    # ---- batched interface (what the engine uses) ----
+    def _rays(self):
+        if self._ray is None and self.cfg.is_lidar:
+            self._ray = OE.ray_tables(self.cfg.n_rays, self.device)
+        return self._ray if self._ray is not None else (None, None)
+
+    @property
+    def _has_hits(self):
+        return self.cfg.is_lidar and self.cfg.n_obs > 0
+
+    def reset_batch(self, seeds, want_graph: bool = False):
+        """seeds: int64 tensor / array [B] -> BatchState (and the GraphsTuple batch if asked)."""
+        cfg, dev = self.cfg, self.device
+        seeds = torch.as_tensor(np.asarray(seeds, dtype=np.int64) if not torch.is_tensor(seeds) else seeds).to(dev)
+        B = int(seeds.shape[0])
+        n, sd = cfg.n_agents, cfg.state_dim
+        agent = torch.empty(B, n, sd, device=dev)
+        goal = torch.empty(B, n, sd, device=dev)
+        obst = torch.empty(B, cfg.n_obs, cfg.obst_stride, device=dev) if cfg.n_obs > 0 else None
+        OE.env_reset(cfg, seeds, agent, goal, obst)
+        hits, g = None, None
+        rc, rs = self._rays()
+        if self._has_hits or want_graph:
+            hits = torch.empty(B, n, cfg.top_k, 2, device=dev) if self._has_hits else None
+            g = OE.alloc_graph(cfg, B, dev) if want_graph else None
+            if self._has_hits:
+                OE.env_step(cfg, agent, None, goal, obst, None, rc, rs, None, hits, None, None, g)
+            else:
+                OE.graph_materialize(cfg, agent, goal, obst, None, g)
+        st = BatchState(agent, goal, obst, hits)
+        return (st, self._graphs(st, g)) if want_graph else st
+
+    def step_batch(self, st: BatchState, action: torch.Tensor, want_graph: bool = False):
+        """-> (next BatchState, reward [B], cost [B,n,2][, GraphsTuple batch])."""
+        cfg, dev = self.cfg, self.device
+        B = st.agent.shape[0]
+        n = cfg.n_agents
+        nx = torch.empty_like(st.agent)
+        nh = torch.empty_like(st.hits) if st.hits is not None else None
+        rew = torch.empty(B, device=dev)
+        cost = torch.empty(B, n, 2, device=dev)
+        g = OE.alloc_graph(cfg, B, dev) if want_graph else None
+        rc, rs = self._rays()
+        OE.env_step(cfg, st.agent, action.contiguous(), st.goal, st.obst, st.hits, rc, rs, nx, nh, rew, cost, g)
+        nst = BatchState(nx, st.goal, st.obst, nh)
+        if want_graph:
+            return nst, rew, cost, self._graphs(nst, g)
+        return nst, rew, cost
+
+    def graph_batch(self, st: BatchState) -> GraphsTuple:
+        g = OE.alloc_graph(self.cfg, st.agent.shape[0], self.device)
+        OE.graph_materialize(self.cfg, st.agent, st.goal, st.obst, st.hits, g)
+        return self._graphs(st, g)
+
+    def _env_states(self, st: BatchState):
+        raise NotImplementedError
+
+    def _graphs(self, st: BatchState, g: dict) -> GraphsTuple:
+        return GraphsTuple(g["n_node"], g["n_edge"], g["nodes"], g["edges"], g["states"], g["receivers"], g["senders"],
+                           g["node_type"], self._env_states(st), None)
+
+    # ---- reference single-graph interface = B = 1 view ----
+    @staticmethod
+    def _squeeze(graph: GraphsTuple) -> GraphsTuple:
+        sq = lambda x: x[0] if torch.is_tensor(x) else x
+        es = graph.env_states
+        es = type(es)(*[_sq_tree(v) for v in es])
+        return GraphsTuple(*[sq(getattr(graph, f)) for f in GraphsTuple._fields[:8]], es, None)
+
+    def reset(self, key) -> GraphsTuple:
+        """key: an integer seed (the reference passes a JAX PRNGKey; its threefry stream is not reproducible here)."""
+        seed = int(key.reshape(-1)[-1]) if hasattr(key, "reshape") else int(key)
+        _, g = self.reset_batch(np.array([seed], dtype=np.int64), want_graph=True)
+        return self._squeeze(g)
+
+    def _state_of(self, graph: GraphsTuple) -> BatchState:
+        raise NotImplementedError
+
+    def step(self, graph: GraphsTuple, action, get_eval_info: bool = False) -> StepResult:
+        st = self._state_of(graph)
+        action = torch.as_tensor(action, dtype=torch.float32, device=self.device).reshape(1, self.num_agents, 2)
+        nst, rew, cost, g = self.step_batch(st, action, want_graph=True)
+        return StepResult(self._squeeze(g), rew[0], cost[0], torch.tensor(False), {})
+
+    def get_cost(self, graph: GraphsTuple):
+        st = self._state_of(graph)
+        zero = torch.zeros(1, self.num_agents, 2, device=self.device)
+        return self.step_batch(st, zero)[2][0]                # cost is a function of the pre-step graph only
+
+    def get_graph(self, env_state, lidar_data=None) -> GraphsTuple:
+        raise NotImplementedError
+
+    def render_video(self, *args, **kwargs):
+        raise NotImplementedError("rendering is outside the hot-path scope of this build (SURVEY §2 row 22)")
+
+
+def _sq_tree(v):
+    if torch.is_tensor(v):
+        return v[0]
+    if isinstance(v, tuple) and hasattr(v, "_fields"):
+        return type(v)(*[_sq_tree(x) for x in v])
+    return v

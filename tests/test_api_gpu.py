@@ -1,0 +1,141 @@
+"""The drop-in Python surface (dgppo.env / dgppo.algo / dgppo.trainer, train.py) on the GPU: single-graph env API vs the
+oracle, algo act/step/collect/update/save/load, lazy rollout.graph, Trainer loop and the train.py CLI."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import env_np as E
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("env_id,n,obs", [("LidarSpread", 4, 2), ("MPETarget", 3, 0), ("MPESpread", 3, 3), ("LidarTarget", 3, 1)])
+def test_single_graph_env_api_matches_oracle(cuda, env_id, n, obs):
+    from dgppo.env import make_env
+    env = make_env(env_id, n, num_obs=obs)
+    ocfg = E.EnvCfg(E.KIND_NAMES[env_id], n_agents=n, n_obs=obs)
+    assert (env.state_dim, env.node_dim, env.edge_dim, env.action_dim, env.n_cost) == (4, 7, 4, 2, 2)
+    assert env.max_episode_steps == 128 and env.dt == 0.03 and env.area_size == 1.5
+    g = env.reset(1234)
+    N_, E_ = ocfg.num_nodes, ocfg.num_edges
+    assert g.nodes.shape == (N_, 7) and g.edges.shape == (E_, 4) and g.states.shape == (N_, 4)
+    assert g.receivers.shape == g.senders.shape == (E_,) and g.node_type.shape == (N_,)
+    assert int(g.n_node) == N_ and int(g.n_edge) == E_ and g.is_single
+    np.testing.assert_array_equal(_np(g.type_states(0, n)), _np(g.states[:n]))
+    agent, goal = _np(g.type_states(0, n))[None], _np(g.type_states(1, n))[None]
+    if ocfg.is_lidar:
+        rec = np.zeros((1, obs, 16), np.float32)
+        ob = g.env_states.obstacle
+        rec[0, :, 0:2], rec[0, :, 2], rec[0, :, 3], rec[0, :, 4] = _np(ob.center), _np(ob.width), _np(ob.height), _np(ob.theta)
+        rec[0, :, 5], rec[0, :, 6] = np.cos(rec[0, :, 4]), np.sin(rec[0, :, 4])
+        rec[0, :, 8:] = _np(ob.points).reshape(obs, 8)
+        hits = _np(g.type_states(2, n * 8))[None, :, :2].reshape(1, n, 8, 2)
+        obst = rec
+    else:
+        obst = _np(g.type_states(2, obs))[None] if obs > 0 else None
+        hits = None
+    action = np.random.default_rng(0).uniform(-1.3, 1.3, size=(n, 2)).astype(np.float32)
+    res = env.step(g, torch.from_numpy(action))
+    want = E.env_step(ocfg, agent, goal, obst, hits, action[None], E.ray_table(32))
+    np.testing.assert_allclose(_np(res.reward), want["reward"][0], atol=1e-7)
+    np.testing.assert_allclose(_np(res.cost), want["cost"][0], atol=1e-6)
+    np.testing.assert_allclose(_np(res.graph.states[:n]), want["next_agent"][0], atol=1e-7)
+    np.testing.assert_array_equal(_np(res.graph.receivers), want["graph"]["receivers"][0])
+    np.testing.assert_array_equal(_np(res.graph.senders), want["graph"]["senders"][0])
+    np.testing.assert_allclose(_np(res.graph.edges), want["graph"]["edges"][0], atol=1e-6)
+    np.testing.assert_allclose(_np(env.get_cost(g)), want["cost"][0], atol=1e-6)
+    assert not bool(res.done) and res.info == {}
+
+
+def _mk_algo(env, batch_size, seed=0, train_steps=100):
+    from dgppo.algo import make_algo
+    return make_algo(algo="dgppo", env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+                     action_dim=env.action_dim, n_agents=env.num_agents, cost_weight=0.0, cbf_weight=1.0, actor_gnn_layers=2,
+                     Vl_gnn_layers=2, Vh_gnn_layers=1, rnn_layers=1, lr_actor=3e-4, lr_Vl=1e-3, lr_Vh=1e-3, max_grad_norm=2.0,
+                     alpha=10.0, cbf_eps=1e-2, seed=seed, batch_size=batch_size, use_rnn=True, use_lstm=False, coef_ent=1e-2,
+                     rnn_step=16, gamma=0.99, clip_eps=0.25, lagr_init=0.5, lr_lagr=1e-7, train_steps=train_steps,
+                     cbf_schedule=True, cost_schedule=False)
+
+
+def test_algo_surface_collect_update_save_load(cuda, tmp_path):
+    from dgppo.env import make_env
+    env = make_env("LidarSpread", 3, max_step=32, num_obs=2)
+    algo = _mk_algo(env, batch_size=8 * 32)
+    assert algo.init_rnn_state.shape == (1, 3, 1, 64) and float(algo.init_rnn_state.abs().max()) == 0
+    cfgd = algo.config
+    for k in ("gamma", "lr_actor", "lr_Vl", "lr_Vh", "batch_size", "clip_eps", "gae_lambda", "coef_ent", "rnn_step", "alpha",
+              "cbf_eps", "cbf_weight", "cbf_schedule", "Vh_gnn_layers"):
+        assert k in cfgd
+    p = algo.params
+    assert set(p) == {"policy", "Vl", "Vh"} and "PolicyNet_0" in p["policy"]["params"]
+    g = env.reset(7)
+    a, h = algo.act(g, algo.init_rnn_state)
+    assert a.shape == (3, 2) and h.shape == (1, 3, 1, 64) and float(a.abs().max()) <= 1
+    a2, lp, h2 = algo.step(g, algo.init_rnn_state, 99)
+    assert a2.shape == (3, 2) and lp.shape == (3,) and torch.allclose(h, h2)
+    keys = np.arange(1, 17)
+    ro = algo.collect(None, keys)
+    B, T = 16, 32
+    assert ro.actions.shape == (B, T, 3, 2) and ro.log_pis.shape == (B, T, 3) and ro.rewards.shape == (B, T)
+    assert ro.costs.shape == (B, T, 3, 2) and ro.rnn_states.shape == (B, T, 1, 3, 1, 64) and ro.dones.shape == (B, T)
+    assert ro.length == B and ro.time_horizon == T and ro.n_data == B * T
+    # lazy graphs: [B, T, N, ...], next_graph[t] == graph[t+1], contents equal the oracle's get_graph
+    ocfg = E.EnvCfg(E.LIDAR_SPREAD, n_agents=3, n_obs=2)
+    assert ro.graph.nodes.shape == (B, T, ocfg.num_nodes, 7) and ro.next_graph.senders.shape == (B, T, ocfg.num_edges)
+    np.testing.assert_array_equal(_np(ro.graph.nodes[:, 1:]), _np(ro.next_graph.nodes[:, :-1]))
+    st = ro.graph.states
+    hits = _np(st[:, 5, 6:6 + 24, :2]).reshape(B, 3, 8, 2)
+    gg = E.get_graph(ocfg, _np(st[:, 5, :3]), _np(st[:, 5, 3:6]), None, hits)
+    np.testing.assert_array_equal(_np(ro.graph.receivers[:, 5]), gg["receivers"])
+    np.testing.assert_array_equal(_np(ro.graph.edges[:, 5]), gg["edges"])
+    before = algo.params["policy"]["params"]["OutputDenseMean"]["kernel"].copy()
+    info = algo.update(ro, 3)
+    assert info["policy/has_nan"] == 0 and np.isfinite(info["policy/loss"])
+    after = algo.params["policy"]["params"]["OutputDenseMean"]["kernel"]
+    assert not np.array_equal(before, after)
+    algo.save(str(tmp_path), 3)
+    assert sorted(os.listdir(tmp_path / "3")) == ["Vh.pkl", "Vl.pkl", "actor.pkl"]
+    algo2 = _mk_algo(env, batch_size=8 * 32, seed=5)
+    algo2.load(str(tmp_path), 3)
+    np.testing.assert_array_equal(algo2.params["policy"]["params"]["OutputDenseMean"]["kernel"], after)
+    a3, _ = algo2.act(g, algo2.init_rnn_state)
+    a4, _ = algo.act(g, algo.init_rnn_state)
+    assert torch.equal(a3, a4)
+
+
+def test_trainer_loop_and_metrics(cuda, tmp_path):
+    from dgppo.env import make_env
+    from dgppo.trainer.trainer import Trainer
+    env, env_test = make_env("MPETarget", 3, max_step=16, num_obs=0), make_env("MPETarget", 3, max_step=16, num_obs=0)
+    algo = _mk_algo(env, batch_size=16 * 16, train_steps=2)
+    tr = Trainer(env=env, env_test=env_test, algo=algo, gamma=0.99, n_env_train=32, n_env_test=8, log_dir=str(tmp_path / "run"),
+                 seed=0, params={"run_name": "t", "training_steps": 2, "eval_interval": 1, "eval_epi": 1, "save_interval": 2})
+    tr.train()
+    assert tr.update_steps == 3                                      # steps + 1 iterations (trainer.py:103)
+    rows = [json.loads(l) for l in open(tmp_path / "run" / "metrics.jsonl")]
+    keys = set().union(*[set(r) for r in rows])
+    for k in ("eval/reward", "eval/reward_final", "eval/cost", "eval/unsafe_frac", "Vl/loss", "Vh/loss_Vh", "policy/loss",
+              "policy/clip_frac", "policy/entropy", "policy/total_variation_dist", "eval/safe_data"):
+        assert k in keys, k
+    assert sorted(os.listdir(tmp_path / "run" / "models")) == ["0", "2"]
+
+
+def test_train_py_cli(cuda, tmp_path):
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--env", "LidarSpread", "-n", "3", "--algo", "dgppo", "--obs", "1",
+           "--steps", "1", "--n-env-train", "16", "--batch-size", "2048", "--n-env-test", "4", "--eval-interval", "1",
+           "--save-interval", "1", "--log-dir", str(tmp_path / "logs")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "step:   0" in out.stdout and "unsafe_frac" in out.stdout
+    runs = os.listdir(tmp_path / "logs" / "LidarSpread" / "dgppo")
+    assert len(runs) == 1 and os.path.exists(tmp_path / "logs" / "LidarSpread" / "dgppo" / runs[0] / "config.yaml")
