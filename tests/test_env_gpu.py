@@ -209,3 +209,36 @@ def test_randn_moments_and_determinism(cuda):
     assert torch.isfinite(x).all()
     O.randn(124, 0, y)
     assert not torch.equal(x, y)
+
+
+def test_generic_kernel_path_matches_specialised(cuda, monkeypatch):
+    """LiDAR envs normally run the specialised n_rays == 32 kernel; the generic kernel (other ray counts, forced here with
+    DGPPO_GENERIC_ENV_KERNEL) must give the same bits, and so must a non-32 ray fan against the oracle."""
+    cfg, ocfg = _mk("LidarSpread", 8, 3)
+    B = 96
+    agent, goal, obst, action = _random_state(ocfg, B, seed=21)
+    tab = E.ray_table(32)
+    hits, _ = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)
+    fast = _run_step(cfg, ocfg, agent, goal, obst, hits, action, cuda)
+    monkeypatch.setenv("DGPPO_GENERIC_ENV_KERNEL", "1")
+    gen = _run_step(cfg, ocfg, agent, goal, obst, hits, action, cuda)
+    monkeypatch.delenv("DGPPO_GENERIC_ENV_KERNEL")
+    for k in ("next_agent", "next_hits", "reward", "cost"):
+        np.testing.assert_array_equal(fast[k].view(np.uint32), gen[k].view(np.uint32), err_msg=k)
+    _assert_graph_equal(fast["graph"], gen["graph"])
+    # 16 rays, top-4: generic kernel vs oracle
+    from dgppo_amd import _native as N, ops_env as O
+    cfg16 = N.make_env_cfg(0, 5, 2, n_rays=16, top_k=4)
+    o16 = E.EnvCfg(0, n_agents=5, n_obs=2, n_rays=16, top_k=4)
+    agent, goal, obst, action = _random_state(o16, 32, seed=22)
+    tab16 = E.ray_table(16)
+    hits, _ = E.lidar_sense(o16, agent[..., :2], obst, *tab16)
+    want = E.env_step(o16, agent, goal, obst, hits, action, tab16)
+    rc, rs = O.ray_tables(16, cuda)
+    nx = torch.empty(32, 5, 4, device=cuda); nh = torch.empty(32, 5, 4, 2, device=cuda)
+    rew = torch.empty(32, device=cuda); cost = torch.empty(32, 5, 2, device=cuda)
+    g = O.alloc_graph(cfg16, 32, cuda)
+    O.env_step(cfg16, _to(agent, cuda), _to(action, cuda), _to(goal, cuda), _to(obst, cuda), _to(hits, cuda), rc, rs, nx, nh, rew, cost, g)
+    np.testing.assert_array_equal(nh.cpu().numpy().view(np.uint32), want["next_hits"].view(np.uint32))
+    np.testing.assert_array_equal(cost.cpu().numpy().view(np.uint32), want["cost"].view(np.uint32))
+    _assert_graph_equal({k: v.cpu().numpy() for k, v in g.items()}, want["graph"])
