@@ -65,8 +65,16 @@ __global__ void __launch_bounds__(256) ln_relu_bwd_kernel(const float* __restric
     const float m2 = wave_sum(dxh * xhat) * (1.0f / 64.0f);
     dx[o] = rstd * (dxh - m1 - xhat * m2);
   }
-  atomicAdd(dgamma + lane, dg);
-  atomicAdd(dbeta + lane, db);
+  // per-workgroup reduction of the 4 waves' partial sums, then one atomic per column
+  __shared__ float red[2][4][64];
+  red[0][threadIdx.x >> 6][lane] = dg;
+  red[1][threadIdx.x >> 6][lane] = db;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6;
+    const float v = red[which][0][lane] + red[which][1][lane] + red[which][2][lane] + red[which][3][lane];
+    atomicAdd((which ? dbeta : dgamma) + lane, v);
+  }
 }
 
 extern "C" int32_t dgppo_ln_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
@@ -85,7 +93,7 @@ extern "C" int32_t dgppo_ln_relu_bwd(const float* x, const float* y, const float
   DGPPO_REQUIRE(M >= 0, "ln_relu_bwd: M < 0");
   if (M == 0) return 0;
   DGPPO_REQUIRE(x && y && stats && gamma && dy && dx && dgamma && dbeta, "ln_relu_bwd: NULL operand");
-  const int grid = min(cdiv(M, 4), 1024);
+  const int grid = min(cdiv(M, 4), 512);
   hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma, dy, dx, dgamma,
                      dbeta, M);
   DGPPO_LAUNCH_CHECK();

@@ -1,0 +1,75 @@
+"""Developer tool: GPU time of the network building blocks at training sizes (minibatch of 16384 LidarSpread n=8 graphs)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dgppo_amd import _native as N, ops_nn as K
+
+dev = torch.device("cuda:0")
+R = 131072          # agent rows of a minibatch (16384 graphs x 8)
+Ro = 16384 * 72
+
+
+def timeit(name, fn, iters=20, flops=None, bytes_=None):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    extra = ""
+    if flops:
+        extra += f"  {flops / us / 1e6:7.1f} TFLOP/s"
+    if bytes_:
+        extra += f"  {bytes_ / us / 1e3:7.0f} GB/s"
+    print(f"{name:44s} {us:9.1f} us{extra}", flush=True)
+
+
+def dense_case(M, Kd, Nd, trans=False, act=0):
+    X = torch.randn(M, Kd, device=dev)
+    W = torch.randn(Nd, Kd, device=dev) if trans else torch.randn(Kd, Nd, device=dev)
+    b = torch.randn(Nd, device=dev)
+    Y = torch.empty(M, Nd, device=dev)
+    timeit(f"dense_fwd M={M} K={Kd} N={Nd} trans={int(trans)}", lambda: K.dense_fwd(X, W, b, Y, act=act, trans_w=trans),
+           flops=2.0 * M * Kd * Nd, bytes_=4.0 * M * (Kd + Nd))
+    dW = torch.zeros(Kd, Nd, device=dev); db = torch.zeros(Nd, device=dev)
+    if not trans:
+        timeit(f"dense_bwd_w M={M} K={Kd} N={Nd}", lambda: K.dense_bwd_w(X, Y, dW, db), flops=2.0 * M * Kd * Nd,
+               bytes_=4.0 * M * (Kd + Nd))
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which in ("all", "dense"):
+    for (M, Kd, Nd, tr) in [(R, 144, 64, False), (R, 64, 64, False), (R, 64, 192, False), (R, 48, 32, False), (R, 32, 96, False),
+                            (R, 8, 24, False), (Ro, 8, 32, False), (R, 64, 144, True), (R, 192, 64, True), (R, 64, 64, True),
+                            (R, 64, 4, False), (32768, 144, 64, False), (32768, 64, 64, False), (32768, 64, 192, False)]:
+        dense_case(M, Kd, Nd, tr)
+if which in ("all", "elem"):
+    x = torch.randn(R, 64, device=dev); g = torch.ones(64, device=dev); b = torch.zeros(64, device=dev)
+    y = torch.empty_like(x); st = torch.empty(R, 2, device=dev); dx = torch.empty_like(x)
+    dg = torch.zeros(64, device=dev); dbb = torch.zeros(64, device=dev)
+    timeit("ln_relu_fwd R x 64", lambda: K.ln_relu_fwd(x, g, b, y, st), bytes_=4.0 * R * 128)
+    timeit("ln_relu_bwd R x 64", lambda: K.ln_relu_bwd(x, y, st, g, x, dx, dg, dbb), bytes_=4.0 * R * 256)
+    timeit("relu_bwd R x 64", lambda: K.relu_bwd(dx, y), bytes_=4.0 * R * 128)
+    gi = torch.randn(R, 192, device=dev); Wh = torch.randn(64, 192, device=dev) * 0.1; bh = torch.zeros(64, device=dev)
+    hs = torch.empty(R, 64, device=dev); hp = torch.empty(R, 64, device=dev); gt = torch.empty(R, 256, device=dev)
+    timeit("gru_fwd n_seq=8192 T=16", lambda: K.gru_fwd(gi, Wh, bh, None, hs, hp, gt, R // 16, 16, 8))
+    dgi = torch.empty(R, 192, device=dev); dgh = torch.empty(R, 192, device=dev)
+    timeit("gru_bwd n_seq=8192 T=16", lambda: K.gru_bwd(hs, Wh, hp, gt, dgi, dgh, R // 16, 16, 8))
+    h0 = torch.randn(32768, 64, device=dev); gi1 = torch.randn(32768, 192, device=dev); hs1 = torch.empty(32768, 64, device=dev)
+    timeit("gru_fwd rollout n_seq=32768 T=1", lambda: K.gru_fwd(gi1, Wh, bh, h0, hs1, None, None, 32768, 1, 8))
+if which in ("all", "attn"):
+    cfg = N.make_env_cfg(0, 8, 3)
+    for G in (16384, 4096):
+        Rg = G * 8
+        for (F, Kp) in ((8, 48), (32, 144)):
+            qt = torch.randn(Rg, 3 * F, device=dev); Xa = torch.randn(Rg, F, device=dev); Xo = torch.randn(G * 72, F, device=dev)
+            ef = torch.randn(Rg, 24, 4, device=dev); em = (torch.rand(Rg, 24, device=dev) > 0.3).float()
+            em[:, 8:16] = 1.0
+            z = torch.empty(Rg, Kp, device=dev); at = torch.empty(Rg, 24, 3, device=dev)
+            timeit(f"attn_fwd G={G} F={F}", lambda: K.attn_fwd(cfg, F, 3, Kp, qt, Xa, Xo, ef, em, z, at, G))
+            dq = torch.empty_like(qt); dXa = torch.empty_like(Xa); dXo = torch.empty_like(Xo)
+            timeit(f"attn_bwd G={G} F={F}", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, dXa, dXo, G))
