@@ -11,6 +11,7 @@
 // so this file only does: graph features, logits against RAW sender features, masked softmax, aggregation of raw
 // features, and the matching backward.  const(i,h) (the key bias) cancels in the softmax.
 #include "common.h"
+#include <stdlib.h>
 
 struct Topo {
   int n, ng, gs, os, per, lidar, spread;  // per = k (LiDAR) or n_obs (MPE)
@@ -214,7 +215,7 @@ struct AttnArgs {
   int G;
 };
 
-__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256) attn_fwd_valu_kernel(AttnArgs a) {
   extern __shared__ float sm[];
   const Topo& t = a.t;
   const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256) attn_bwd_valu_kernel(AttnArgs a) {
   extern __shared__ float sm[];
   const Topo& t = a.t;
   const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -380,6 +381,382 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
   }
 }
 
+
+// =====================================================================================================================
+// Matrix-core attention.  Per graph (one workgroup, 4 waves) everything is a small dense product through LDS:
+//   L [nH x Ns]  = Qt [nH x F] * Xs^T            logits of every (agent, head) against every node      (MFMA)
+//   a            = masked softmax of L gathered at the agent's S slots                                   (half-wave shuffles)
+//   P [nH x Ns]  = a scattered back to node columns (0 elsewhere)
+//   Zx [nH x F]  = P * Xs                          aggregated sender features                            (MFMA)
+//   ze [nH x 4]  = sum_s a * edge feature                                                                 (VALU, tiny)
+// backward:  dA = dZx * Xs^T (MFMA) (+ dze . e), softmax backward, dQt = dL * Xs (MFMA),
+//            dXs = P^T * dZx + dL^T * Qt (MFMA), agents also get the direct x_i part of dzcat.
+// v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], D[row = (lane>>4)*4 + r][col = lane&15].
+// Padding rows/columns of every operand are zero-filled so that they cannot leak into valid outputs.
+// =====================================================================================================================
+using f32x4g = __attribute__((ext_vector_type(4))) float;
+#ifdef DGPPO_STAMPS
+__device__ unsigned long long g_astamps[32];
+#define ASTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_astamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int32_t dgppo_debug_stamps_attn(unsigned long long* out) {
+  return (int32_t)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_astamps), sizeof(unsigned long long) * 32);
+}
+#else
+#define ASTAMP(i)
+#endif
+
+struct AttnDims {
+  int n, H, F, S, Ns, nH, RT, CT, Fl, Ll, W;   // RT = ceil(nH/16), CT = ceil(Ns/16), W = lanes per (agent, head) pair
+};
+__host__ __device__ inline AttnDims attn_dims(const Topo& t, int F, int H) {
+  AttnDims d;
+  d.n = t.n; d.H = H; d.F = F; d.S = t.S; d.Ns = t.Ns; d.nH = t.n * H;
+  d.RT = (d.nH + 15) / 16; d.CT = (d.Ns + 15) / 16;
+  d.Fl = F + 1; d.Ll = d.CT * 16 + 1; d.W = (t.S > 32) ? 64 : 32;
+  return d;
+}
+static size_t attn_mfma_smem(const AttnDims& d, bool bwd) {
+  size_t fl = (size_t)d.CT * 16 * d.Fl        // s_x   node features (rows >= Ns zero)
+              + (size_t)d.RT * 16 * d.Fl      // s_q   qt (rows >= nH zero)
+              + (size_t)d.RT * 16 * d.Ll      // s_L   logits -> P
+              + 8 + (size_t)d.n * d.S * 5     // s_e (4, float4-aligned) + s_m (1)
+              + 2 * (size_t)d.nH * ((d.S + 3) & ~3);   // compact per-pair rows (s_a, and s_c in the backward)
+  if (bwd) fl += (size_t)d.RT * 16 * d.Ll     // s_D   dA -> dL (dense)
+                 + (size_t)d.RT * 16 * (d.F + 5);  // s_z   dz (aggregated part), rows >= nH zero
+  return fl * sizeof(float);
+}
+
+__device__ inline float red_max(float v, int W) {
+  for (int o = W >> 1; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, W));
+  return v;
+}
+__device__ inline float red_sum(float v, int W) {
+  for (int o = W >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o, W);
+  return v;
+}
+
+// C[rows x cols] (tile list dealt round-robin to the 4 waves) = A[rows x K] * B[K x cols]; element accessors are lambdas
+template <typename FA, typename FB, typename FC>
+__device__ inline void mfma_tiles(int RTn, int CTn, int K4, int wave, int lane, FA fa, FB fb, FC fc) {
+  const int li = lane & 15, lq = lane >> 4;
+  for (int tile = wave; tile < RTn * CTn; tile += 4) {
+    const int rt = tile / CTn, ct = tile - rt * CTn;
+    f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+    // fragments of 4 k-steps are fetched together (one LDS round trip), then 4 MFMAs issue back to back
+    int k4 = 0;
+    for (; k4 + 4 <= K4; k4 += 4) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { av[u] = fa(rt * 16 + li, (k4 + u) * 4 + lq); bv[u] = fb((k4 + u) * 4 + lq, ct * 16 + li); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; k4 < K4; ++k4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa(rt * 16 + li, k4 * 4 + lq), fb(k4 * 4 + lq, ct * 16 + li), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fc(rt * 16 + lq * 4 + r, ct * 16 + li, acc[r]);
+  }
+}
+
+
+// Issue up to MAXIT float4 loads per lane back to back (all in flight together), then hand them to `put`.
+template <int MAXIT, typename FL, typename FP>
+__device__ inline void stage4(int count4, int tid, FL load, FP put) {
+  float4 v[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int idx = tid + it * 256;
+    v[it] = (idx < count4) ? load(idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int idx = tid + it * 256;
+    if (idx < count4) put(idx, v[it]);
+  }
+  for (int idx = tid + MAXIT * 256; idx < count4; idx += 256) put(idx, load(idx));
+}
+__device__ inline void put4(float* d, float4 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+
+#define ATT_SMAX 64   // max slots per agent handled by the per-pair register row
+
+__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ float sm[];
+  const Topo& t = a.t;
+  const AttnDims d = attn_dims(t, a.F, a.H);
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = d.n, S = d.S, Ns = d.Ns, F = d.F, H = d.H, Fl = d.Fl, Ll = d.Ll, nH = d.nH;
+  const int Sp = (S + 3) & ~3;
+  float* s_x = sm;
+  float* s_q = s_x + d.CT * 16 * Fl;
+  float* s_L = s_q + d.RT * 16 * Fl;
+  float* s_e = sm + (((d.CT * 16 * Fl + d.RT * 16 * Fl + d.RT * 16 * Ll) + 3) & ~3);   // float4-aligned
+  float* s_m = s_e + n * S * 4;
+  float* s_a = s_m + n * S;               // compact [nH][Sp]: logits at the slots -> attention weights
+  ASTAMP(0);
+  // ---- stage operands (zero padding): every global load of the lane is issued before the first LDS store ----
+  {
+    const int F4 = F >> 2;
+    const float4* xa = reinterpret_cast<const float4*>(a.Xa + (size_t)g * n * F);
+    const float4* xo = reinterpret_cast<const float4*>(a.Xo + (size_t)g * (Ns - n) * F);
+    const float4* q4 = reinterpret_cast<const float4*>(a.qt + (size_t)g * nH * F);
+    const float4* e4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
+    const float* mk = a.emask + (size_t)g * n * S;
+    const int nA = n * F4, nX = Ns * F4, nXp = d.CT * 16 * F4, nQ = nH * F4, nQp = d.RT * 16 * F4, nE = n * S;
+    float4 vx[4], vq[2], ve[2];
+    float vm[2];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { const int idx = tid + it * 256; vx[it] = (idx < nA) ? xa[idx] : ((idx < nX) ? xo[idx - nA] : z4); }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { const int idx = tid + it * 256; vq[it] = (idx < nQ) ? q4[idx] : z4; ve[it] = (idx < nE) ? e4[idx] : z4; vm[it] = (idx < nE) ? mk[idx] : 0.0f; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { const int idx = tid + it * 256; if (idx < nXp) { const int nd = idx / F4, q = idx - nd * F4; put4(s_x + nd * Fl + 4 * q, vx[it]); } }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < nQp) { const int row = idx / F4, q = idx - row * F4; put4(s_q + row * Fl + 4 * q, vq[it]); }
+      if (idx < nE) { reinterpret_cast<float4*>(s_e)[idx] = ve[it]; s_m[idx] = vm[it]; }
+    }
+    // sizes beyond the register budget (large n): plain loops
+    for (int idx = tid + 1024; idx < nXp; idx += 256) { const int nd = idx / F4, q = idx - nd * F4; put4(s_x + nd * Fl + 4 * q, (idx < nA) ? xa[idx] : ((idx < nX) ? xo[idx - nA] : z4)); }
+    for (int idx = tid + 512; idx < nQp; idx += 256) { const int row = idx / F4, q = idx - row * F4; put4(s_q + row * Fl + 4 * q, (idx < nQ) ? q4[idx] : z4); }
+    for (int idx = tid + 512; idx < nE; idx += 256) { reinterpret_cast<float4*>(s_e)[idx] = e4[idx]; s_m[idx] = mk[idx]; }
+  }
+  __syncthreads();
+  ASTAMP(1);
+  // ---- L = Qt * Xs^T ----
+  mfma_tiles(d.RT, d.CT, F / 4, wave, lane,
+             [&](int row, int k) { return s_q[row * Fl + k]; },
+             [&](int k, int col) { return s_x[col * Fl + k]; },
+             [&](int row, int col, float v) { s_L[row * Ll + col] = v; });
+  __syncthreads();
+  ASTAMP(2);
+  // ---- gather the logits at the agent's slots into the compact rows (masked slots -> -inf) ----
+  for (int idx = tid; idx < nH * Sp; idx += 256) {
+    const int pair = idx / Sp, s = idx - pair * Sp, i = pair / H;
+    float l = -INFINITY;
+    if (s < S && s_m[i * S + s] != 0.0f) l = s_L[pair * Ll + sender_node(t, i, s)];
+    s_a[idx] = l;
+  }
+  __syncthreads();
+  ASTAMP(3);
+  // ---- 8 lanes per (agent, head): softmax over the compact row (<= 8 slots per lane in registers, 3-step xor
+  //      reductions) + the edge-feature aggregation; afterwards every lane helps clearing s_L for the scatter of P ----
+  const int Wd = F + 4;
+  float* zc = a.zcat + (size_t)g * n * a.Kp;
+  for (int p0 = 0; p0 < nH; p0 += 32) {
+    const int pair = p0 + (tid >> 3), sub = tid & 7;
+    const bool live = pair < nH;
+    const int i = live ? pair / H : 0, h = live ? pair - (pair / H) * H : 0;
+    float l[ATT_SMAX / 8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < ATT_SMAX / 8; ++j) {
+      const int sl = sub + 8 * j;
+      l[j] = (live && sl < S) ? s_a[pair * Sp + sl] : -INFINITY;
+      mx = fmaxf(mx, l[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 8)); mx = fmaxf(mx, __shfl_xor(mx, 2, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+    float den = 0.0f;
+#pragma unroll
+    for (int j = 0; j < ATT_SMAX / 8; ++j) {
+      if (sub + 8 * j < S) { const float ev = (l[j] == -INFINITY) ? 0.0f : expf(l[j] - mx); l[j] = ev; den += ev; }
+    }
+    den += __shfl_xor(den, 1, 8); den += __shfl_xor(den, 2, 8); den += __shfl_xor(den, 4, 8);
+    const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
+    float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < ATT_SMAX / 8; ++j) {
+      const int sl = sub + 8 * j;
+      if (live && sl < S) {
+        const float av = l[j] * inv;
+        s_a[pair * Sp + sl] = av;
+        if (av != 0.0f) {   // masked slots may carry 5e5 / NaN edge features: skip, never multiply
+          const float4 e = reinterpret_cast<const float4*>(s_e)[i * S + sl];
+          z0 = fmaf(av, e.x, z0); z1 = fmaf(av, e.y, z1); z2 = fmaf(av, e.z, z2); z3 = fmaf(av, e.w, z3);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { z0 += __shfl_xor(z0, o, 8); z1 += __shfl_xor(z1, o, 8); z2 += __shfl_xor(z2, o, 8); z3 += __shfl_xor(z3, o, 8); }
+    if (live && sub == 0) *reinterpret_cast<float4*>(zc + i * a.Kp + F + h * Wd + F) = make_float4(z0, z1, z2, z3);
+  }
+  for (int idx = tid; idx < d.RT * 16 * Ll; idx += 256) s_L[idx] = 0.0f;
+  __syncthreads();
+  ASTAMP(4);
+  // ---- scatter P, write the attention weights ----
+  for (int idx = tid; idx < n * S * H; idx += 256) {
+    const int h = idx % H, is = idx / H, i = is / S, s = is - i * S;
+    const float av = s_a[(i * H + h) * Sp + s];
+    a.attn[(size_t)g * n * S * H + idx] = av;
+    if (av != 0.0f) s_L[(i * H + h) * Ll + sender_node(t, i, s)] = av;
+  }
+  __syncthreads();
+  ASTAMP(5);
+  // ---- Zx = P * Xs, written straight into zcat; the direct x_i part and the constant column ----
+  mfma_tiles(d.RT, (F + 15) / 16, d.CT * 4, wave, lane,
+             [&](int row, int k) { return s_L[row * Ll + k]; },
+             [&](int k, int col) { return (col < F) ? s_x[k * Fl + col] : 0.0f; },
+             [&](int row, int col, float v) {
+               if (row < nH && col < F) { const int i = row / H, h = row - i * H; zc[i * a.Kp + F + h * Wd + col] = v; }
+             });
+  for (int idx = tid; idx < n * F; idx += 256) {
+    const int i = idx / F, f = idx - i * F;
+    zc[i * a.Kp + f] = s_x[i * Fl + f];
+  }
+  const int kc = F + H * Wd;
+  for (int idx = tid; idx < n * (a.Kp - kc); idx += 256) {
+    const int i = idx / (a.Kp - kc), c = kc + idx - i * (a.Kp - kc);
+    zc[i * a.Kp + c] = (c == kc) ? 1.0f : 0.0f;
+  }
+  ASTAMP(6);
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
+  extern __shared__ float sm[];
+  const Topo& t = a.t;
+  const AttnDims d = attn_dims(t, a.F, a.H);
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = d.n, S = d.S, Ns = d.Ns, F = d.F, H = d.H, Fl = d.Fl, Ll = d.Ll, nH = d.nH;
+  const int Wd = F + 4, Zl = F + 5, Sp = (S + 3) & ~3;
+  float* s_x = sm;
+  float* s_q = s_x + d.CT * 16 * Fl;
+  float* s_P = s_q + d.RT * 16 * Fl;
+  float* s_e = sm + (((d.CT * 16 * Fl + d.RT * 16 * Fl + d.RT * 16 * Ll) + 3) & ~3);   // float4-aligned
+  float* s_c = s_e + n * S * 4;           // compact [nH][Sp]: dA at the slots -> dl     (the forward's s_m + s_a space)
+  float* s_a = s_c + nH * Sp;             // compact [nH][Sp]: attention weights
+  float* s_D = s_a + nH * Sp;
+  float* s_z = s_D + d.RT * 16 * Ll;
+  const float* dzc = a.dzcat + (size_t)g * n * a.Kp;
+  {
+    const int F4 = F >> 2, W4 = Wd >> 2;       // Wd = F + 4, Kp and F are multiples of 4 -> 16-byte aligned pieces
+    const float4* xa = reinterpret_cast<const float4*>(a.Xa + (size_t)g * n * F);
+    const float4* xo = reinterpret_cast<const float4*>(a.Xo + (size_t)g * (Ns - n) * F);
+    const float4* q4 = reinterpret_cast<const float4*>(a.qt + (size_t)g * nH * F);
+    const float4* e4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
+    const float* at = a.attn + (size_t)g * n * S * H;
+    const int nA = n * F4, nX = Ns * F4, nXp = d.CT * 16 * F4, nQ = nH * F4, nQp = d.RT * 16 * F4, nE = n * S;
+    const int nZp = d.RT * 16 * W4, nAt = n * S * H;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ldz = [&](int idx) {
+      const int row = idx / W4, q = idx - row * W4;
+      if (row >= nH) return z4;
+      const int i = row / H, h = row - i * H;
+      return *reinterpret_cast<const float4*>(dzc + i * a.Kp + F + h * Wd + 4 * q);
+    };
+    float4 vx[4], vq[2], ve[2], vz[2];
+    float va[3];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { const int idx = tid + it * 256; vx[it] = (idx < nA) ? xa[idx] : ((idx < nX) ? xo[idx - nA] : z4); }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { const int idx = tid + it * 256; vq[it] = (idx < nQ) ? q4[idx] : z4; ve[it] = (idx < nE) ? e4[idx] : z4; vz[it] = (idx < nZp) ? ldz(idx) : z4; }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) { const int idx = tid + it * 256; va[it] = (idx < nAt) ? at[idx] : 0.0f; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { const int idx = tid + it * 256; if (idx < nXp) { const int nd = idx / F4, q = idx - nd * F4; put4(s_x + nd * Fl + 4 * q, vx[it]); } }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < nQp) { const int row = idx / F4, q = idx - row * F4; put4(s_q + row * Fl + 4 * q, vq[it]); }
+      if (idx < nE) reinterpret_cast<float4*>(s_e)[idx] = ve[it];
+      if (idx < nZp) { const int row = idx / W4, q = idx - row * W4; put4(s_z + row * Zl + 4 * q, vz[it]); }
+    }
+    auto puta = [&](int idx, float v) { const int h = idx % H, is = idx / H, i = is / S, s = is - i * S; s_a[(i * H + h) * Sp + s] = v; };
+#pragma unroll
+    for (int it = 0; it < 3; ++it) { const int idx = tid + it * 256; if (idx < nAt) puta(idx, va[it]); }
+    for (int idx = tid + 1024; idx < nXp; idx += 256) { const int nd = idx / F4, q = idx - nd * F4; put4(s_x + nd * Fl + 4 * q, (idx < nA) ? xa[idx] : ((idx < nX) ? xo[idx - nA] : z4)); }
+    for (int idx = tid + 512; idx < nQp; idx += 256) { const int row = idx / F4, q = idx - row * F4; put4(s_q + row * Fl + 4 * q, (idx < nQ) ? q4[idx] : z4); }
+    for (int idx = tid + 512; idx < nE; idx += 256) reinterpret_cast<float4*>(s_e)[idx] = e4[idx];
+    for (int idx = tid + 512; idx < nZp; idx += 256) { const int row = idx / W4, q = idx - row * W4; put4(s_z + row * Zl + 4 * q, ldz(idx)); }
+    for (int idx = tid + 768; idx < nAt; idx += 256) puta(idx, at[idx]);
+    for (int idx = tid; idx < d.RT * 16 * Ll; idx += 256) s_P[idx] = 0.0f;
+    if (Sp != S) for (int idx = tid; idx < nH; idx += 256) for (int s = S; s < Sp; ++s) s_a[idx * Sp + s] = 0.0f;
+  }
+  __syncthreads();
+  // P scatter (for dXs) and dA = dZx * Xs^T
+  for (int idx = tid; idx < nH * S; idx += 256) {
+    const int pair = idx / S, s = idx - pair * S, i = pair / H;
+    const float av = s_a[pair * Sp + s];
+    if (av != 0.0f) s_P[pair * Ll + sender_node(t, i, s)] = av;
+  }
+  mfma_tiles(d.RT, d.CT, F / 4, wave, lane,
+             [&](int row, int k) { return s_z[row * Zl + k]; },
+             [&](int k, int col) { return s_x[col * Fl + k]; },
+             [&](int row, int col, float v) { s_D[row * Ll + col] = v; });
+  __syncthreads();
+  // gather dA at the slots (+ the edge-feature term) into the compact rows
+  for (int idx = tid; idx < nH * Sp; idx += 256) {
+    const int pair = idx / Sp, s = idx - pair * Sp, i = pair / H;
+    float dA = 0.0f;
+    if (s < S && s_a[idx] != 0.0f) {
+      dA = s_D[pair * Ll + sender_node(t, i, s)];
+      const float* dz = s_z + pair * Zl + F;
+      const float4 e = reinterpret_cast<const float4*>(s_e)[i * S + s];
+      dA = fmaf(dz[0], e.x, fmaf(dz[1], e.y, fmaf(dz[2], e.z, fmaf(dz[3], e.w, dA))));
+    }
+    s_c[idx] = dA;
+  }
+  __syncthreads();
+  // 8 lanes per (agent, head): softmax backward dl = a * (dA - sum_s a dA); then every lane helps clearing s_D
+  for (int p0 = 0; p0 < nH; p0 += 32) {
+    const int pair = p0 + (tid >> 3), sub = tid & 7;
+    const bool live = pair < nH;
+    float av[ATT_SMAX / 8], dA[ATT_SMAX / 8];
+    float dot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < ATT_SMAX / 8; ++j) {
+      const int sl = sub + 8 * j;
+      av[j] = (live && sl < S) ? s_a[pair * Sp + sl] : 0.0f;
+      dA[j] = (live && sl < S) ? s_c[pair * Sp + sl] : 0.0f;
+      dot = fmaf(av[j], dA[j], dot);
+    }
+    dot += __shfl_xor(dot, 1, 8); dot += __shfl_xor(dot, 2, 8); dot += __shfl_xor(dot, 4, 8);
+#pragma unroll
+    for (int j = 0; j < ATT_SMAX / 8; ++j) {
+      const int sl = sub + 8 * j;
+      if (live && sl < S) s_c[pair * Sp + sl] = av[j] * (dA[j] - dot);
+    }
+  }
+  for (int idx = tid; idx < d.RT * 16 * Ll; idx += 256) s_D[idx] = 0.0f;
+  __syncthreads();
+  for (int idx = tid; idx < nH * S; idx += 256) {
+    const int pair = idx / S, s = idx - pair * S, i = pair / H;
+    const float dl = s_c[pair * Sp + s];
+    if (dl != 0.0f) s_D[pair * Ll + sender_node(t, i, s)] = dl;
+  }
+  __syncthreads();
+  // dQt = dL * Xs
+  float* dq = a.dqt + (size_t)g * nH * F;
+  mfma_tiles(d.RT, (F + 15) / 16, d.CT * 4, wave, lane,
+             [&](int row, int k) { return s_D[row * Ll + k]; },
+             [&](int k, int col) { return (col < F) ? s_x[k * Fl + col] : 0.0f; },
+             [&](int row, int col, float v) { if (row < nH && col < F) dq[row * F + col] = v; });
+  // dXs = P^T * dZx + dL^T * Qt  (+ direct x_i part for agents)
+  if (a.dXa != nullptr) {
+    const int li = lane & 15, lq = lane >> 4;
+    const int FT = (F + 15) / 16;
+    for (int tile = wave; tile < d.CT * FT; tile += 4) {
+      const int rt = tile / FT, ct = tile - rt * FT;
+      f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+      const int nd_a = rt * 16 + li, col_b = ct * 16 + li;
+#pragma unroll 4
+      for (int k4 = 0; k4 < d.RT * 4; ++k4) {
+        const int kk = k4 * 4 + lq;   // (agent, head) row
+        const float bz = (col_b < F) ? s_z[kk * Zl + col_b] : 0.0f;
+        const float bq = (col_b < F) ? s_q[kk * Fl + col_b] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_P[kk * Ll + nd_a], bz, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(s_D[kk * Ll + nd_a], bq, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nd = rt * 16 + lq * 4 + r, f = ct * 16 + li;
+        if (nd >= Ns || f >= F) continue;
+        if (nd < n) a.dXa[((size_t)g * n + nd) * F + f] = acc[r] + dzc[nd * a.Kp + f];
+        else if (a.dXo != nullptr) a.dXo[((size_t)g * (Ns - n) + (nd - n)) * F + f] = acc[r];
+      }
+    }
+  }
+}
+
 static int32_t attn_check(const dgppo_env_cfg* cfg, int F, int H, int Kp, int G, AttnArgs& a) {
   int32_t rc = dgppo_validate_cfg(cfg);
   if (rc) return rc;
@@ -405,7 +782,12 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   const size_t smem = sizeof(float) * ((size_t)t.Ns * (F + 1) + (size_t)t.n * H * (F + 1) + (size_t)t.n * t.S * 5 +
                                        (size_t)t.n * t.S * H);
   DGPPO_REQUIRE(smem <= 64 * 1024, "attn_fwd: graph too large for LDS (%zu B)", smem);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
+  const AttnDims d = attn_dims(t, F, H);
+  const size_t msmem = attn_mfma_smem(d, false);
+  if ((F & 3) == 0 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
@@ -425,7 +807,13 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   const size_t smem = sizeof(float) * ((size_t)t.Ns * (F + 1) + (size_t)t.n * H * (F + 1) + (size_t)t.n * t.S * 4 +
                                        2 * (size_t)t.n * t.S * H + (size_t)t.n * H * (F + 5));
   DGPPO_REQUIRE(smem <= 64 * 1024, "attn_bwd: graph too large for LDS (%zu B)", smem);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
+  const AttnDims d = attn_dims(t, F, H);
+  const size_t msmem = attn_mfma_smem(d, true);
+  // narrow layers (F = 8) are pure latency: there the VALU kernel's shorter dependency chain wins (measured)
+  if ((F & 3) == 0 && F >= 16 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
