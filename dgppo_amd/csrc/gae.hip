@@ -74,6 +74,89 @@ __global__ void gae_kernel(GaeArgs a) {
   }
 }
 
+
+// Faster variant for T + 1 <= 256: thread j owns DP row j (its n*nh constraint values + the cost value) in registers,
+// the env's costs / values are staged in LDS once, and Q = sum_j c_j row_j is a workgroup reduction (wave shuffles, then
+// one LDS hop) instead of a serial loop.  Same recurrences; only the summation order of Q differs (fp32, ~1e-7).
+template <int AHP>
+__global__ void __launch_bounds__(256) gae_rows_kernel(GaeArgs a) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.T, AH = a.AH, n = a.n, nh = a.nh;
+  float* s_cost = sm;                       // [T][AH]
+  float* s_Vh = s_cost + T * AH;            // [T+1][AH]
+  float* s_Vl = s_Vh + (T + 1) * AH;        // [T+1]
+  float* s_rew = s_Vl + (T + 1);            // [T]
+  float* s_part = s_rew + T;                // [2][4][AHP+1]  per-wave partial sums, double buffered
+  const float* costs = a.costs + (size_t)b * T * AH;
+  const float* Vh = a.Vh + (size_t)b * (T + 1) * AH;
+  for (int i = tid; i < T * AH; i += 256) s_cost[i] = costs[i];
+  for (int i = tid; i < (T + 1) * AH; i += 256) s_Vh[i] = Vh[i];
+  for (int i = tid; i < T + 1; i += 256) s_Vl[i] = a.Vl[(size_t)b * (T + 1) + i];
+  for (int i = tid; i < T; i += 256) s_rew[i] = a.rewards[(size_t)b * T + i];
+  __syncthreads();
+  const int j = tid;                        // DP row of this thread
+  float row[AHP];
+  float rowl = 0.0f;
+#pragma unroll
+  for (int c = 0; c < AHP; ++c) row[c] = (j == 0 && c < AH) ? s_Vh[T * AH + c] : 0.0f;   // row 0 <- V(x_T)
+  if (j == 0) rowl = s_Vl[T];
+  for (int ii = 0; ii < T; ++ii) {
+    const int t = T - 1 - ii;
+    const bool act = j <= ii;
+    float contrib[AHP];
+    float cl = 0.0f;
+    const float cj = (j == 0) ? a.lam_pow[ii] : ((j <= ii) ? a.lam_pow[ii - j] * a.one_minus_lam : 0.0f);
+    if (act) {
+      const float l = -s_rew[t];
+      rowl = l + a.gamma * rowl;
+      cl = cj * rowl;
+    }
+#pragma unroll
+    for (int ag = 0; ag < AHP; ag += 1) {
+      // (1 - gamma) * max_h hs[t][agent], broadcast reads
+      if (ag < AH) {
+        const int agent = ag / nh;
+        float m = s_cost[t * AH + agent * nh];
+        for (int h = 1; h < nh; ++h) m = fmaxf(m, s_cost[t * AH + agent * nh + h]);
+        if (act) row[ag] = fmaxf(s_cost[t * AH + ag], a.one_minus_gamma * m + a.gamma * row[ag]);
+        contrib[ag] = act ? cj * row[ag] : 0.0f;
+      } else {
+        contrib[ag] = 0.0f;
+      }
+    }
+    // workgroup reduction of AH + 1 values
+#pragma unroll
+    for (int c = 0; c < AHP; ++c) {
+      float v = contrib[c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      contrib[c] = v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cl += __shfl_xor(cl, o);
+    float* part = s_part + (ii & 1) * 4 * (AHP + 1);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < AHP; ++c) part[wave * (AHP + 1) + c] = contrib[c];
+      part[wave * (AHP + 1) + AHP] = cl;
+    }
+    // row insertion for the next step (utils.py:53-54)
+    if (j == ii + 1) {
+#pragma unroll
+      for (int c = 0; c < AHP; ++c) row[c] = (c < AH) ? s_Vh[t * AH + c] : 0.0f;
+      rowl = s_Vl[t];
+    }
+    __syncthreads();
+    if (tid <= AH) {
+      const int c = (tid < AH) ? tid : AHP;
+      const float q = part[c] + part[(AHP + 1) + c] + part[2 * (AHP + 1) + c] + part[3 * (AHP + 1) + c];
+      if (tid < AH) a.Qh[((size_t)b * T + t) * AH + tid] = q;
+      else a.Ql[(size_t)b * T + t] = q;
+    }
+  }
+}
+
 extern "C" int32_t dgppo_gae(const float* costs, const float* rewards, const float* Vh, const float* Vl,
                              const float* lam_pow, float gamma, float one_minus_gamma, float one_minus_lam, float* Qh,
                              float* Ql, int32_t B, int32_t T, int32_t n, int32_t nh, void* stream) {
@@ -81,6 +164,18 @@ extern "C" int32_t dgppo_gae(const float* costs, const float* rewards, const flo
   if (B == 0) return 0;
   DGPPO_REQUIRE(costs && rewards && Vh && Vl && lam_pow && Qh && Ql, "gae: NULL operand");
   GaeArgs a{costs, rewards, Vh, Vl, lam_pow, Qh, Ql, B, T, n * nh, n, nh, gamma, one_minus_gamma, one_minus_lam};
+  if (T + 1 <= 256 && a.AH <= 32) {
+    const int ahp = a.AH <= 8 ? 8 : (a.AH <= 16 ? 16 : 32);
+    const size_t fsm = sizeof(float) * ((size_t)T * a.AH + (size_t)(T + 1) * a.AH + (T + 1) + T + 2 * 4 * (ahp + 1));
+    if (fsm <= 64 * 1024) {
+      hipStream_t st = (hipStream_t)stream;
+      if (ahp == 8) hipLaunchKernelGGL(gae_rows_kernel<8>, dim3(B), dim3(256), fsm, st, a);
+      else if (ahp == 16) hipLaunchKernelGGL(gae_rows_kernel<16>, dim3(B), dim3(256), fsm, st, a);
+      else hipLaunchKernelGGL(gae_rows_kernel<32>, dim3(B), dim3(256), fsm, st, a);
+      DGPPO_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const size_t smem = sizeof(float) * ((size_t)(T + 1) * a.AH + (T + 1) + 2 * a.AH);
   DGPPO_REQUIRE(smem <= 150 * 1024, "gae: T*n*nh too large for LDS (%zu B)", smem);
   if (smem > 64 * 1024)

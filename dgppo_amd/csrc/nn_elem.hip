@@ -132,56 +132,86 @@ __device__ inline size_t gru_row(const GruArgs& a, int s, int tau) {
 }
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// SEQ = sequences per workgroup (64: one 16-row tile per wave x all 12 column tiles; 16: one row tile shared by the 4
+// waves, 3 column tiles each — 4x shorter MFMA chain per step for small / latency-bound launches).
+template <int SEQ>
 __global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
   extern __shared__ float sm[];
   float* s_w = sm;                       // [64][GRU_WL]
-  float* s_h = s_w + GRU_H * GRU_WL;     // [GRU_SEQ][GRU_HL]
+  float* s_h = s_w + GRU_H * GRU_WL;     // [SEQ][GRU_HL]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  const int s0 = blockIdx.x * GRU_SEQ;
+  constexpr int NTW = (SEQ == 64) ? 12 : 3;            // column tiles per wave
+  const int rt = (SEQ == 64) ? wave : 0;               // row tile of this wave
+  const int ct0 = (SEQ == 64) ? 0 : wave;              // first column tile; tiles ct0 + 4*j  (gate j of columns 16*wave..)
+  const int s0 = blockIdx.x * SEQ;
   for (int idx = tid; idx < GRU_H * 192; idx += 256) {
     const int k = idx / 192, c = idx - k * 192;
     s_w[k * GRU_WL + c] = a.Wh[idx];
   }
-  for (int idx = tid; idx < GRU_SEQ * GRU_H; idx += 256) {
+  for (int idx = tid; idx < SEQ * GRU_H; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     const int s = s0 + r;
     s_h[r * GRU_HL + c] = (a.h0 != nullptr && s < a.n_seq) ? a.h0[(size_t)s * GRU_H + c] : 0.0f;
   }
   __syncthreads();
+  // this lane's output elements: rows rl = rt*16 + lq*4 + r (r < 4); columns c = tt*16 + li with
+  //   SEQ 64: tt = 0..3 (tiles tt, tt+4, tt+8 = the r|z|n gates of column block tt);  SEQ 16: tt = wave only
+  constexpr int NC = (SEQ == 64) ? 4 : 1;
   for (int tau = 0; tau < a.T; ++tau) {
-    f32x4 acc[12];
+    // gate inputs of this step: issued before the MFMA loop so that their latency hides behind it
+    float gr[NC][4], gz[NC][4], gn[NC][4];
+    size_t rowi[4];
+    bool ok[4];
 #pragma unroll
-    for (int t = 0; t < 12; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* hrow = s_h + (wave * 16 + li) * GRU_HL;
+    for (int r = 0; r < 4; ++r) {
+      const int s = s0 + rt * 16 + lq * 4 + r;
+      ok[r] = s < a.n_seq;
+      rowi[r] = ok[r] ? gru_row(a, s, tau) : 0;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int c = ((SEQ == 64) ? q : wave) * 16 + li;
+        const float* g = a.gi + rowi[r] * 192;
+        gr[q][r] = ok[r] ? g[c] : 0.0f; gz[q][r] = ok[r] ? g[64 + c] : 0.0f; gn[q][r] = ok[r] ? g[128 + c] : 0.0f;
+      }
+    }
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* hrow = s_h + (rt * 16 + li) * GRU_HL;
+#pragma unroll 4
     for (int k0 = 0; k0 < GRU_H; k0 += 4) {
       const float av = hrow[k0 + lq];
       const float* wrow = s_w + (k0 + lq) * GRU_WL + li;
 #pragma unroll
-      for (int t = 0; t < 12; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[t * 16], acc[t], 0, 0, 0);
+      for (int t = 0; t < NTW; ++t) {
+        const int ct = (SEQ == 64) ? t : (ct0 + 4 * t);     // SEQ 16: tiles wave, wave+4, wave+8 = r|z|n of column block `wave`
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[ct * 16], acc[t], 0, 0, 0);
+      }
     }
-    __syncthreads();  // every wave has read its rows of s_h before anyone overwrites them
+    __syncthreads();  // every wave has read s_h before anyone overwrites it
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int c = tt * 16 + li;
+    for (int q = 0; q < NC; ++q) {
+      const int cb = (SEQ == 64) ? q : wave;
+      const int c = cb * 16 + li;
       const float bn = a.bhn[c];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int rl = wave * 16 + lq * 4 + r;
-        const int s = s0 + rl;
-        if (s >= a.n_seq) continue;
-        const size_t row = gru_row(a, s, tau);
-        const float* g = a.gi + row * 192;
+        if (!ok[r]) continue;
+        const int rl = rt * 16 + lq * 4 + r;
+        const float ar = (SEQ == 64) ? acc[q][r] : acc[0][r];
+        const float az = (SEQ == 64) ? acc[q + 4][r] : acc[1][r];
+        const float an = (SEQ == 64) ? acc[q + 8][r] : acc[2][r];
         const float hp = s_h[rl * GRU_HL + c];
-        const float rg = sigmoidf_(g[c] + acc[tt][r]);
-        const float zg = sigmoidf_(g[64 + c] + acc[tt + 4][r]);
-        const float hn = acc[tt + 8][r] + bn;
-        const float ng = tanhf(g[128 + c] + rg * hn);
+        const float rg = sigmoidf_(gr[q][r] + ar);
+        const float zg = sigmoidf_(gz[q][r] + az);
+        const float hn = an + bn;
+        const float ng = tanhf(gn[q][r] + rg * hn);
         const float hnew = (1.0f - zg) * ng + zg * hp;
-        a.hs[row * GRU_H + c] = hnew;
-        if (a.hprev != nullptr) a.hprev[row * GRU_H + c] = hp;
+        a.hs[rowi[r] * GRU_H + c] = hnew;
+        if (a.hprev != nullptr) a.hprev[rowi[r] * GRU_H + c] = hp;
         if (a.gates != nullptr) {
-          float* gs = a.gates + row * 256;
+          float* gs = a.gates + rowi[r] * 256;
           gs[c] = rg; gs[64 + c] = zg; gs[128 + c] = ng; gs[192 + c] = hn;
         }
         s_h[rl * GRU_HL + c] = hnew;
@@ -192,39 +222,58 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
 }
 
 // BPTT: walks tau = T-1 .. 0 carrying dh; the recurrent product dh_prev += dgh * Wh^T runs on the matrix cores.
+// The saved gates / hprev / upstream gradient of step tau-1 are fetched while step tau's product runs.
+template <int SEQ>
 __global__ void __launch_bounds__(256) gru_bwd_kernel(GruArgs a) {
   extern __shared__ float sm[];
   float* s_w = sm;                        // [64][GRU_WL]   Wh
-  float* s_g = s_w + GRU_H * GRU_WL;      // [GRU_SEQ][GRU_WL]  dgh of this step
-  float* s_dh = s_g + GRU_SEQ * GRU_WL;   // [GRU_SEQ][GRU_HL]  carried dh
+  float* s_g = s_w + GRU_H * GRU_WL;      // [SEQ][GRU_WL]  dgh of this step
+  float* s_dh = s_g + SEQ * GRU_WL;       // [SEQ][GRU_HL]  carried dh
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  const int s0 = blockIdx.x * GRU_SEQ;
+  const int s0 = blockIdx.x * SEQ;
+  constexpr int EPT = SEQ * GRU_H / 256;  // elements per thread in the elementwise phase (16 or 4)
   for (int idx = tid; idx < GRU_H * 192; idx += 256) {
     const int k = idx / 192, c = idx - k * 192;
     s_w[k * GRU_WL + c] = a.Wh[idx];
   }
-  for (int idx = tid; idx < GRU_SEQ * GRU_HL; idx += 256) s_dh[idx] = 0.0f;
+  for (int idx = tid; idx < SEQ * GRU_HL; idx += 256) s_dh[idx] = 0.0f;
+  float rg[EPT], zg[EPT], ng[EPT], hn[EPT], hp[EPT], du[EPT];
+  auto fetch = [&](int tau) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int idx = tid + e * 256, rl = idx >> 6, c = idx & 63;
+      const int sq = s0 + rl;
+      if (sq < a.n_seq) {
+        const size_t row = gru_row(a, sq, tau);
+        const float* gs = a.gates + row * 256;
+        rg[e] = gs[c]; zg[e] = gs[64 + c]; ng[e] = gs[128 + c]; hn[e] = gs[192 + c];
+        hp[e] = a.hprev[row * GRU_H + c];
+        du[e] = a.dhs[row * GRU_H + c];
+      } else {
+        rg[e] = zg[e] = ng[e] = hn[e] = hp[e] = du[e] = 0.0f;
+      }
+    }
+  };
+  fetch(a.T - 1);
   __syncthreads();
   for (int tau = a.T - 1; tau >= 0; --tau) {
-    // phase A: gate gradients, elementwise
-    for (int idx = tid; idx < GRU_SEQ * GRU_H; idx += 256) {
-      const int rl = idx >> 6, c = idx & 63;
-      const int s = s0 + rl;
+    // phase A: gate gradients, elementwise (operands already in registers)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int idx = tid + e * 256, rl = idx >> 6, c = idx & 63;
+      const int sq = s0 + rl;
       float dar = 0.f, daz = 0.f, dan = 0.f, dhn = 0.f, dhz = 0.f;
-      if (s < a.n_seq) {
-        const size_t row = gru_row(a, s, tau);
-        const float* gs = a.gates + row * 256;
-        const float rg = gs[c], zg = gs[64 + c], ng = gs[128 + c], hn = gs[192 + c];
-        const float hp = a.hprev[row * GRU_H + c];
-        const float dh = s_dh[rl * GRU_HL + c] + a.dhs[row * GRU_H + c];
-        const float dz = dh * (hp - ng);
-        const float dn = dh * (1.0f - zg);
-        dan = dn * (1.0f - ng * ng);
-        dhn = dan * rg;
-        dar = dan * hn * rg * (1.0f - rg);
-        daz = dz * zg * (1.0f - zg);
-        dhz = dh * zg;
+      if (sq < a.n_seq) {
+        const size_t row = gru_row(a, sq, tau);
+        const float dh = s_dh[rl * GRU_HL + c] + du[e];
+        const float dz = dh * (hp[e] - ng[e]);
+        const float dn = dh * (1.0f - zg[e]);
+        dan = dn * (1.0f - ng[e] * ng[e]);
+        dhn = dan * rg[e];
+        dar = dan * hn[e] * rg[e] * (1.0f - rg[e]);
+        daz = dz * zg[e] * (1.0f - zg[e]);
+        dhz = dh * zg[e];
         float* o = a.dgi + row * 192;
         o[c] = dar; o[64 + c] = daz; o[128 + c] = dan;
         float* p = a.dgh + row * 192;
@@ -236,23 +285,31 @@ __global__ void __launch_bounds__(256) gru_bwd_kernel(GruArgs a) {
       s_dh[rl * GRU_HL + c] = dhz;
     }
     __syncthreads();
+    if (tau > 0) fetch(tau - 1);          // in flight during the product below
     // phase B: dh_prev[row, c] += sum_k dgh[row, k] * Wh[c, k]
-    f32x4 acc[4];
+    if constexpr (SEQ == 64) {
+      f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* grow = s_g + (wave * 16 + li) * GRU_WL;
-    for (int k0 = 0; k0 < 192; k0 += 4) {
-      const float av = grow[k0 + lq];
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* grow = s_g + (wave * 16 + li) * GRU_WL;
+#pragma unroll 4
+      for (int k0 = 0; k0 < 192; k0 += 4) {
+        const float av = grow[k0 + lq];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float bv = s_w[(t * 16 + li) * GRU_WL + k0 + lq];  // B[k][j] = Wh[j][k]
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_w[(t * 16 + li) * GRU_WL + k0 + lq], acc[t], 0, 0, 0);
       }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_dh[(wave * 16 + lq * 4 + r) * GRU_HL + t * 16 + li] += acc[t][r];
+    } else {   // one 16-row tile, wave w owns output columns 16w .. 16w+15
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* grow = s_g + li * GRU_WL;
+#pragma unroll 8
+      for (int k0 = 0; k0 < 192; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[k0 + lq], s_w[(wave * 16 + li) * GRU_WL + k0 + lq], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_dh[(lq * 4 + r) * GRU_HL + wave * 16 + li] += acc[r];
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_dh[(wave * 16 + lq * 4 + r) * GRU_HL + t * 16 + li] += acc[t][r];
     __syncthreads();
   }
 }
@@ -272,8 +329,13 @@ extern "C" int32_t dgppo_gru_fwd(const float* gi, const float* Wh, const float* 
   if (rc) return rc;
   if (n_seq == 0) return 0;
   DGPPO_REQUIRE(gi && Wh && bhn && hs, "gru_fwd: NULL operand");
-  const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)GRU_SEQ * GRU_HL);
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(n_seq, GRU_SEQ)), dim3(256), smem, (hipStream_t)stream, a);
+  if (cdiv(n_seq, 64) < 192) {   // fewer than ~3/4 of a wave of 64-sequence workgroups: shorten the per-step chain instead
+    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)16 * GRU_HL);
+    hipLaunchKernelGGL(gru_fwd_kernel<16>, dim3(cdiv(n_seq, 16)), dim3(256), smem, (hipStream_t)stream, a);
+  } else {
+    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)64 * GRU_HL);
+    hipLaunchKernelGGL(gru_fwd_kernel<64>, dim3(cdiv(n_seq, 64)), dim3(256), smem, (hipStream_t)stream, a);
+  }
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
@@ -287,8 +349,13 @@ extern "C" int32_t dgppo_gru_bwd(const float* dhs, const float* Wh, const float*
   if (rc) return rc;
   if (n_seq == 0) return 0;
   DGPPO_REQUIRE(dhs && Wh && hprev && gates && dgi && dgh, "gru_bwd: NULL operand");
-  const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)GRU_SEQ * GRU_WL + (size_t)GRU_SEQ * GRU_HL);
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(n_seq, GRU_SEQ)), dim3(256), smem, (hipStream_t)stream, a);
+  if (cdiv(n_seq, 64) < 192) {
+    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)16 * GRU_WL + (size_t)16 * GRU_HL);
+    hipLaunchKernelGGL(gru_bwd_kernel<16>, dim3(cdiv(n_seq, 16)), dim3(256), smem, (hipStream_t)stream, a);
+  } else {
+    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)64 * GRU_WL + (size_t)64 * GRU_HL);
+    hipLaunchKernelGGL(gru_bwd_kernel<64>, dim3(cdiv(n_seq, 64)), dim3(256), smem, (hipStream_t)stream, a);
+  }
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
