@@ -208,9 +208,15 @@ def main():
         "last_info": {k: info[k] for k in ("policy/loss", "Vl/loss", "Vh/loss_Vh", "eval/safe_data")},
     }
     if rl is not None:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_env_step_traffic.json")
+        if os.path.exists(tpath) and B == 4096 and args.env == "LidarSpread" and args.num_agents == 8 and args.obs == 3:
+            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE), see profiles/README.md
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch_api_fetch_x2"]
         out["roofline"] = {"bound": "hbm", "kernel": "env_step_kernel (dynamics + raycast + top-k + reward/cost + GraphsTuple emit)",
                            "achieved": rl["api"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rl["api"]["gbs"] / HBM_PEAK_GBS,
-                           "traffic": None, "bytes_per_env_step": rl["api"]["bytes_per_env_step"],
+                           "traffic": traffic, "traffic_source": "profiles/r01_env_step_traffic.json (rocprofv3 --pmc, offline)",
+                           "algorithmic_bytes_per_launch": rl["api"]["bytes_per_env_step"] * B, "bytes_per_env_step": rl["api"]["bytes_per_env_step"],
                            "us_per_launch": rl["api"]["us_per_launch"], "kernel_env_steps_per_s": rl["api"]["env_steps_per_s"],
                            "compact": rl["compact"]}
     if not args.no_cpu_baseline and world == 1:
