@@ -130,6 +130,9 @@ def main():
     from dgppo_amd import _native as N, engine as EN, init, dist as D
     D.init(backend="nccl", device=device)
     allreduce = D.make_allreduce(world)          # RCCL all-reduce of each net's flat gradient buffer per minibatch step
+    if allreduce is not None:                    # build the communicator outside any timed region
+        allreduce(torch.zeros(1 << 16, device=device))
+        torch.cuda.synchronize()
 
     cfg = N.make_env_cfg(N.ENV_KINDS[args.env], args.num_agents, args.obs)
     T = 128
