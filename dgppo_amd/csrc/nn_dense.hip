@@ -8,6 +8,15 @@
 #include "common.h"
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+#ifdef DGPPO_STAMPS
+__device__ unsigned long long g_dstamps[32];
+#define DSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int32_t dgppo_debug_stamps_dense(unsigned long long* out) {
+  return (int32_t)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dstamps), sizeof(unsigned long long) * 32);
+}
+#else
+#define DSTAMP(i)
+#endif
 
 #define DENSE_ROWS 64  // rows per workgroup (4 waves x 16)
 
@@ -22,94 +31,252 @@ struct DenseArgs {
   int trans_w;     // use W^T: result[m,n] = sum_k X[m,k] * W[n,k]
 };
 
-// One workgroup = 64 rows x all N columns.  The X tile is staged once in LDS (coalesced, float4 when aligned).  The
-// N/16 column tiles are dealt to CG = min(4, tiles) column groups (one or more waves each), the 4 row tiles of 16 rows to
-// the remaining 4/CG row groups.  K is walked in chunks of 64: a wave first pulls its W fragments of the chunk into
-// registers (16 x NTW values per lane, read once per workgroup from L1/L2), then runs every row tile it owns against
-// them, so the inner loop issues one LDS read (the A fragment) per NTW MFMAs and no global loads.
-template <int NTW, int RTW>
-__global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
-  extern __shared__ float xs[];  // [64][Kl]
-  constexpr int CG = (RTW == 4) ? 4 : ((RTW == 2) ? 2 : 1);   // column groups
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * DENSE_ROWS;
-  const int K = a.K, N = a.N, Kl = K | 1;                      // odd row stride: conflict-free A-fragment reads
-  const bool vec = ((K & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
-  if (vec) {
-    const int K4 = K >> 2;
-    for (int idx = tid; idx < DENSE_ROWS * K4; idx += 256) {
-      const int r = idx / K4, q = idx - r * K4;
-      const int row = row0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < a.M) v = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + 4 * q);
-      float* d = xs + r * Kl + 4 * q;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-  } else {
-    for (int idx = tid; idx < DENSE_ROWS * K; idx += 256) {
-      const int r = idx / K, k = idx - r * K;
-      const int row = row0 + r;
-      xs[r * Kl + k] = (row < a.M) ? a.X[(size_t)row * a.ldx + k] : 0.0f;
-    }
-  }
-  __syncthreads();
-  const int li = lane & 15, lq = lane >> 4;
-  const int cg = wave % CG, rg = wave / CG;
-  f32x4 acc[RTW][NTW];
+
+// Stage a [rows x 4*W4] tile of a row-major matrix into LDS (row stride Ls floats).  Loads are issued in batches of 8
+// float4 per lane before any LDS store, so 8 global requests per lane are in flight instead of one.
+template <bool ALIGNED_LDS>
+__device__ inline void stage_tile_f4(const float* __restrict__ src, int ld, int row0, int row_end, int rows, int W4,
+                                     float* __restrict__ dst, int Ls, int tid) {
+  const int total = rows * W4;
+  for (int base = 0; base < total; base += 8 * 256) {
+    float4 v[8];
 #pragma unroll
-  for (int r = 0; r < RTW; ++r)
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int kc = 0; kc < K; kc += 64) {
-    float breg[16][NTW];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const int k = kc + kk * 4 + lq;
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const int col = (cg + CG * t) * 16 + li;
-        float bv = 0.0f;
-        if (k < K && col < N) bv = a.trans_w ? a.W[(size_t)col * a.ldw + k] : a.W[(size_t)k * a.ldw + col];
-        breg[kk][t] = bv;
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256 + tid;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < total) {
+        const int r = idx / W4, q = idx - r * W4;
+        if (row0 + r < row_end) v[u] = *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + 4 * q);
       }
     }
 #pragma unroll
-    for (int r = 0; r < RTW; ++r) {
-      const float* xrow = xs + ((rg * RTW + r) * 16 + li) * Kl + kc + lq;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const float av = (kc + kk * 4 + lq < K) ? xrow[kk * 4] : 0.0f;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, breg[kk][t], acc[r][t], 0, 0, 0);
-      }
-    }
-  }
-  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int col = (cg + CG * t) * 16 + li;
-    if (col >= N) continue;
-    const float bb = a.bias ? a.bias[col] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < RTW; ++r) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = row0 + (rg * RTW + r) * 16 + lq * 4 + j;
-        if (row >= a.M) continue;
-        float v = acc[r][t][j] + bb;
-        float* dst = a.Y + (size_t)row * a.ldy + col;
-        if (a.accumulate) v += *dst;
-        if (a.act == 1) v = fmaxf(v, 0.0f);
-        *dst = v;
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256 + tid;
+      if (idx < total) {
+        const int r = idx / W4, q = idx - r * W4;
+        float* d = dst + r * Ls + 4 * q;
+        if (ALIGNED_LDS) *reinterpret_cast<float4*>(d) = v[u];
+        else { d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w; }
       }
     }
   }
 }
 
-template <int NTW, int RTW>
+// Persistent workgroups: each keeps ITS W fragments for the whole K in registers (read once from L2), then walks row
+// tiles with a stride of gridDim.x.  Per tile: the NEXT tile's X rows are fetched from HBM into registers while the
+// current tile (already in LDS) runs on the matrix cores, then written to the other LDS buffer — one LDS-only barrier
+// per tile.  Everything in the tile loop is branch-free: K is padded (with zeros, in LDS and in the W fragments) to
+// KQ*16, out-of-range rows are clamped on load and masked on store.
+//   CG  column groups (waves that split the N/16 column tiles), RG = 4/CG row groups, RTW row tiles (16 rows) per wave,
+//   NTW column tiles per wave, KQ = padded K / 16.  Rows per tile RB = 16*RTW*RG.
+template <int NTW, int RTW, int CG, int KQ, bool ACC>
+__global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
+  extern __shared__ float xs_all[];
+  constexpr int RG = 4 / CG, RB = 16 * RTW * RG;
+  constexpr int KS = KQ * 4;                                   // k-steps of 4 (one MFMA each)
+  constexpr int Kl = KQ * 16 + 1;                              // odd LDS row stride: conflict-free A-fragment reads
+  constexpr int SLOTS = RB * KS;                               // float4 slots per tile
+  constexpr int PF = (SLOTS + 255) / 256;                      // prefetch registers (float4) per lane
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int cg = wave % CG, rg = wave / CG;
+  const int K = a.K, N = a.N;
+  const bool vec = ((K & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+  const int K4 = K >> 2;
+  const int n_tiles = (a.M + RB - 1) / RB;
+  DSTAMP(0);
+  // ---- W fragments and bias of this wave ----
+  float breg[KS][NTW], bias[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = (cg + CG * t) * 16 + li;
+    bias[t] = (a.bias && col < N) ? a.bias[col] : 0.0f;
+  }
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = kk * 4 + lq;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = (cg + CG * t) * 16 + li;
+      float bv = 0.0f;
+      if (k < K && col < N) bv = a.trans_w ? a.W[(size_t)col * a.ldw + k] : a.W[(size_t)k * a.ldw + col];
+      breg[kk][t] = bv;
+    }
+  }
+  float4 pf[PF];
+  auto fetch = [&](int tile) {          // global -> registers; every load is issued before anything waits
+    const int row0 = tile * RB;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      int idx = u * 256 + tid;
+      idx = idx < SLOTS ? idx : SLOTS - 1;                     // duplicates are benign
+      const int r = idx / KS, q = idx - r * KS;
+      int row = row0 + r;
+      row = row < a.M ? row : a.M - 1;
+      const int qc = q < K4 ? q : K4 - 1;
+      pf[u] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + 4 * qc);   // zero padding applied in commit
+    }
+  };
+  auto commit = [&](int b) {            // registers -> LDS buffer b
+    float* xs = xs_all + b * (RB * Kl);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      int idx = u * 256 + tid;
+      idx = idx < SLOTS ? idx : SLOTS - 1;
+      const int r = idx / KS, q = idx - r * KS;
+      float* d = xs + r * Kl + 4 * q;
+      const bool pad = q >= K4;                                // touching pf only here keeps the loads in flight
+      d[0] = pad ? 0.0f : pf[u].x; d[1] = pad ? 0.0f : pf[u].y; d[2] = pad ? 0.0f : pf[u].z; d[3] = pad ? 0.0f : pf[u].w;
+    }
+  };
+  auto stage_scalar = [&](int tile, int b) {   // unaligned / K % 4 != 0 fallback (no prefetch)
+    float* xs = xs_all + b * (RB * Kl);
+    const int row0 = tile * RB;
+    for (int idx = tid; idx < RB * (KQ * 16); idx += 256) {
+      const int r = idx / (KQ * 16), k = idx - r * (KQ * 16);
+      xs[r * Kl + k] = (row0 + r < a.M && k < K) ? a.X[(size_t)(row0 + r) * a.ldx + k] : 0.0f;
+    }
+  };
+  f32x4 acc[RTW][NTW];
+  f32x4 yold[ACC ? RTW : 1][ACC ? NTW : 1];
+  auto load_yold = [&](int tile) {      // accumulate mode: the old Y tile, issued before the prefetch (in-order vmcnt)
+    if constexpr (ACC) {
+      const int row0 = tile * RB;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        int col = (cg + CG * t) * 16 + li;
+        col = col < N ? col : N - 1;
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int row = row0 + (rg * RTW + r) * 16 + lq * 4 + j;
+            row = row < a.M ? row : a.M - 1;
+            yold[r][t][j] = a.Y[(size_t)row * a.ldy + col];
+          }
+      }
+    }
+  };
+  auto compute = [&](int b) {
+    const float* xs = xs_all + b * (RB * Kl) + (rg * RTW * 16 + li) * Kl + lq;
+#pragma unroll
+    for (int r = 0; r < RTW; ++r)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KS; c += 16) {
+      float areg[RTW][16];
+#pragma unroll
+      for (int r = 0; r < RTW; ++r)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+          if (c + kk < KS) areg[r][kk] = xs[r * 16 * Kl + (c + kk) * 4];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+            if (c + kk < KS)
+              acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[r][kk], breg[c + kk][t], acc[r][t], 0, 0, 0);
+    }
+  };
+  auto epilogue = [&](int tile) {       // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int row0 = tile * RB;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = (cg + CG * t) * 16 + li;
+#pragma unroll
+      for (int r = 0; r < RTW; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = row0 + (rg * RTW + r) * 16 + lq * 4 + j;
+          float v = acc[r][t][j] + bias[t];
+          if constexpr (ACC) v += yold[r][t][j];
+          if (a.act == 1) v = fmaxf(v, 0.0f);
+          if (col < N && row < a.M) a.Y[(size_t)row * a.ldy + col] = v;
+        }
+      }
+    }
+  };
+  // LDS-only barrier: __syncthreads() would also wait for the epilogue's global stores (vmcnt(0)) on every tile.
+  // Y is never re-read across waves, so only the ds_writes have to land before the other waves read them.
+#define DGPPO_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  int tile = blockIdx.x;
+  if (vec) {
+    fetch(tile);
+    commit(0);
+    __syncthreads();
+    DSTAMP(1);
+    int cur = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+      int nxt = tile + gridDim.x;
+      nxt = nxt < n_tiles ? nxt : n_tiles - 1;                 // last round re-fetches a valid tile; never committed-to-use
+      load_yold(tile);
+      fetch(nxt);                                              // in flight during the MFMAs below
+      __builtin_amdgcn_sched_barrier(0);                       // keep the scheduler from sinking the loads past them
+      compute(cur);
+      commit(cur ^ 1);                                         // before the stores: vmcnt retires in order
+      __builtin_amdgcn_sched_barrier(0);
+      epilogue(tile);
+      DGPPO_LDS_BARRIER();
+      cur ^= 1;
+    }
+  } else {
+    for (; tile < n_tiles; tile += gridDim.x) {
+      stage_scalar(tile, 0);
+      load_yold(tile);
+      __syncthreads();
+      compute(0);
+      epilogue(tile);
+      DGPPO_LDS_BARRIER();
+    }
+  }
+#undef DGPPO_LDS_BARRIER
+  DSTAMP(2);
+}
+
+template <int NTW, int RTW, int CG, int KQ, bool ACC>
+static void launch_dense_acc(const DenseArgs& a, hipStream_t s) {
+  constexpr int RB = 16 * RTW * (4 / CG);
+  constexpr size_t smem = 2 * (size_t)RB * (KQ * 16 + 1) * sizeof(float);
+  static_assert(smem <= 160 * 1024, "dense tile exceeds the 160 KB LDS of a gfx950 CU");
+  // persistent grid = what is actually resident (registers and LDS both limit it); queried once per instantiation
+  static thread_local int cap = 0;
+  if (cap == 0) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (smem > 64 * 1024)                          // above the default dynamic-LDS limit: opt in explicitly
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_fwd_kernel<NTW, RTW, CG, KQ, ACC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(
+            &dense_fwd_kernel<NTW, RTW, CG, KQ, ACC>), 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cap = per_cu * cus;
+  }
+  const int n_tiles = cdiv(a.M, RB);
+  const int grid = n_tiles < cap ? n_tiles : cap;
+  hipLaunchKernelGGL((dense_fwd_kernel<NTW, RTW, CG, KQ, ACC>), dim3(grid), dim3(256), smem, s, a);
+}
+
+template <int NTW, int RTW, int CG, int KQ>
+static void launch_dense_kq(const DenseArgs& a, hipStream_t s) {
+  if (a.accumulate) launch_dense_acc<NTW, RTW, CG, KQ, true>(a, s);
+  else launch_dense_acc<NTW, RTW, CG, KQ, false>(a, s);
+}
+
+template <int NTW, int RTW, int CG>
 static void launch_dense(const DenseArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)DENSE_ROWS * (a.K | 1) * sizeof(float);
-  hipLaunchKernelGGL((dense_fwd_kernel<NTW, RTW>), dim3(cdiv(a.M, DENSE_ROWS)), dim3(256), smem, s, a);
+  const int kq = cdiv(a.K, 16);                    // padded-K instantiations: 16,32,48,64,96,128,144,192,256
+  if (kq <= 1) launch_dense_kq<NTW, RTW, CG, 1>(a, s);
+  else if (kq == 2) launch_dense_kq<NTW, RTW, CG, 2>(a, s);
+  else if (kq == 3) launch_dense_kq<NTW, RTW, CG, 3>(a, s);
+  else if (kq == 4) launch_dense_kq<NTW, RTW, CG, 4>(a, s);
+  else if (kq <= 6) launch_dense_kq<NTW, RTW, CG, 6>(a, s);
+  else if (kq <= 8) launch_dense_kq<NTW, RTW, CG, 8>(a, s);
+  else if (kq == 9) launch_dense_kq<NTW, RTW, CG, 9>(a, s);
+  else if (kq <= 12) launch_dense_kq<NTW, RTW, CG, 12>(a, s);
+  else launch_dense_kq<NTW, RTW, CG, 16>(a, s);
 }
 
 int32_t dense_fwd_launch(const DenseArgs& a, hipStream_t s) {
@@ -119,12 +286,12 @@ int32_t dense_fwd_launch(const DenseArgs& a, hipStream_t s) {
   DGPPO_REQUIRE(a.ldx >= a.K && a.ldy >= a.N, "dense: leading dimensions too small");
   if (a.M == 0) return 0;
   const int nt = cdiv(a.N, 16);
-  if (nt >= 9) launch_dense<3, 4>(a, s);        // N in (128, 192]
-  else if (nt >= 5) launch_dense<2, 4>(a, s);   // N in (64, 128]
-  else if (nt == 4) launch_dense<1, 4>(a, s);   // N in (48, 64]
-  else if (nt == 3) launch_dense<2, 2>(a, s);   // N in (32, 48]
-  else if (nt == 2) launch_dense<1, 2>(a, s);   // N in (16, 32]
-  else launch_dense<1, 1>(a, s);                // N <= 16
+  if (nt >= 9) launch_dense<3, 2, 4>(a, s);        // N in (128, 192]
+  else if (nt >= 5) launch_dense<2, 2, 4>(a, s);   // N in (64, 128]
+  else if (nt == 4) launch_dense<1, 2, 4>(a, s);   // N in (48, 64]
+  else if (nt == 3) launch_dense<2, 1, 2>(a, s);   // N in (32, 48]
+  else if (nt == 2) launch_dense<1, 1, 2>(a, s);   // N in (16, 32]
+  else launch_dense<1, 1, 1>(a, s);                // N <= 16  (64-row tiles, one row tile per wave)
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
@@ -166,13 +333,7 @@ __global__ void __launch_bounds__(256) dense_bwd_w_kernel(DenseBwdWArgs a) {
   const bool vy = ((N & 3) == 0) && ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dY) & 15) == 0);
   for (int m0 = m_begin; m0 < m_end; m0 += BW_ROWS) {
     if (vx) {
-      const int K4 = K >> 2;
-      for (int idx = tid; idx < BW_ROWS * K4; idx += 256) {
-        const int r = idx / K4, q = idx - r * K4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + r < m_end) v = *reinterpret_cast<const float4*>(a.X + (size_t)(m0 + r) * a.ldx + 4 * q);
-        *reinterpret_cast<float4*>(xs + r * Kl + 4 * q) = v;
-      }
+      stage_tile_f4<true>(a.X, a.ldx, m0, m_end, BW_ROWS, K >> 2, xs, Kl, tid);
     } else {
       for (int idx = tid; idx < BW_ROWS * K; idx += 256) {
         const int r = idx / K, k = idx - r * K;
@@ -180,13 +341,7 @@ __global__ void __launch_bounds__(256) dense_bwd_w_kernel(DenseBwdWArgs a) {
       }
     }
     if (vy) {
-      const int N4 = N >> 2;
-      for (int idx = tid; idx < BW_ROWS * N4; idx += 256) {
-        const int r = idx / N4, q = idx - r * N4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + r < m_end) v = *reinterpret_cast<const float4*>(a.dY + (size_t)(m0 + r) * a.ldy + 4 * q);
-        *reinterpret_cast<float4*>(ys + r * Nl + 4 * q) = v;
-      }
+      stage_tile_f4<true>(a.dY, a.ldy, m0, m_end, BW_ROWS, N >> 2, ys, Nl, tid);
     } else {
       for (int idx = tid; idx < BW_ROWS * N; idx += 256) {
         const int r = idx / N, c = idx - r * N;
