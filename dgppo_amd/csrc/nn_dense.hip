@@ -304,74 +304,153 @@ struct DenseBwdWArgs {
   float* db;  // may be NULL
   int M, K, N;
   int rows_per_block;
+  float* part;        // scratch for per-workgroup partials [grid][part_stride], or NULL: atomicAdd straight into dW/db
+  int part_stride;    // >= K*N + N
 };
 
-// A workgroup walks its chunk of rows in tiles of 32: X[32,K] and dY[32,N] are staged in LDS with coalesced (float4)
-// loads, then wave w accumulates the output row-tiles kt = w, w+4, ... (KTW of them) x all NT column tiles with MFMA over
-// the tile's 8 four-row slabs (A[i=k][kk=m] = X[m][k], B[kk=m][j] = dY[m][j]); column sums for db come from the same
-// LDS tile.  One fp32 atomicAdd per output element per workgroup at the end.
+// A workgroup owns a contiguous chunk of rows and walks it in tiles of 32.  X[32,K] and dY[32,N] tiles live in LDS
+// (double-buffered); the NEXT tile's rows are fetched from HBM into registers while the current one runs on the matrix
+// cores and are written to the other buffer afterwards — one LDS-only barrier per tile (no global stores in the loop, and
+// a __syncthreads() would wait for the prefetch).  Wave w accumulates the output row-tiles kt = w, w+4, ... x all NT
+// column tiles over the tile's 8 four-row slabs (A[i=k][kk=m] = X[m][k], B[kk=m][j] = dY[m][j]).  K and N are padded to
+// KT*16 / NT*16 with zeros in LDS so the loop is branch-free; db's column sums are accumulated per lane from the
+// prefetch registers and reduced once at the end.  Write-out: every workgroup stores its K*N (+N) partial sums to a
+// scratch slab and dense_bwd_w_reduce_kernel folds the slabs into dW/db — with hundreds of workgroups finishing together,
+// atomicAdd on the same K*N addresses serialises (measured: 137 us vs 10 us for K=64, N=4).  Only launches of <= 4
+// workgroups (or a missing scratch buffer) use atomicAdd directly.
 #define BW_ROWS 32
-template <int NT, int KTW>
+template <int NT, int KT>
 __global__ void __launch_bounds__(256) dense_bwd_w_kernel(DenseBwdWArgs a) {
   extern __shared__ float sm[];
+  constexpr int KTW = (KT + 3) / 4;
+  // row strides = 16 mod 32 floats: the four slab rows of a fragment read hit disjoint bank halves
+  constexpr int Kl = (KT & 1) ? KT * 16 : KT * 16 + 16;
+  constexpr int Nl = (NT & 1) ? NT * 16 : NT * 16 + 16;
+  constexpr int BUF = BW_ROWS * (Kl + Nl);
+  constexpr int XQ = KT * 4, YQ = NT * 4;                      // float4 slots per padded row
+  constexpr int PFX = (BW_ROWS * XQ + 255) / 256, PFY = (BW_ROWS * YQ + 255) / 256;
   const int K = a.K, N = a.N;
-  const int Kl = (K + 3) / 4 * 4 + 4, Nl = (N + 3) / 4 * 4 + 4;   // row strides (multiples of 4 floats, not of 32)
-  float* xs = sm;                  // [32][Kl]
-  float* ys = sm + BW_ROWS * Kl;   // [32][Nl]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int m_begin = blockIdx.x * a.rows_per_block;
   const int m_end = min(a.M, m_begin + a.rows_per_block);
+  const bool vec = ((K & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0) &&
+                   ((N & 3) == 0) && ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dY) & 15) == 0);
+  const int K4 = K >> 2, N4 = N >> 2;
   f32x4 acc[KTW][NT];
 #pragma unroll
   for (int i = 0; i < KTW; ++i)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float colsum = 0.0f;
-  const int KT = (K + 15) / 16;
-  const bool vx = ((K & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
-  const bool vy = ((N & 3) == 0) && ((a.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dY) & 15) == 0);
-  for (int m0 = m_begin; m0 < m_end; m0 += BW_ROWS) {
-    if (vx) {
-      stage_tile_f4<true>(a.X, a.ldx, m0, m_end, BW_ROWS, K >> 2, xs, Kl, tid);
-    } else {
-      for (int idx = tid; idx < BW_ROWS * K; idx += 256) {
-        const int r = idx / K, k = idx - r * K;
-        xs[r * Kl + k] = (m0 + r < m_end) ? a.X[(size_t)(m0 + r) * a.ldx + k] : 0.0f;
-      }
+  float4 pfx[PFX], pfy[PFY], csum[PFY];
+#pragma unroll
+  for (int u = 0; u < PFY; ++u) csum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto fetch = [&](int m0) {            // global -> registers (rows clamped; masking happens in commit)
+#pragma unroll
+    for (int u = 0; u < PFX; ++u) {
+      int idx = u * 256 + tid;
+      idx = idx < BW_ROWS * XQ ? idx : BW_ROWS * XQ - 1;
+      const int r = idx / XQ, q = idx - r * XQ;
+      int row = m0 + r;
+      row = row < a.M ? row : a.M - 1;
+      pfx[u] = *reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + 4 * (q < K4 ? q : K4 - 1));
     }
-    if (vy) {
-      stage_tile_f4<true>(a.dY, a.ldy, m0, m_end, BW_ROWS, N >> 2, ys, Nl, tid);
-    } else {
-      for (int idx = tid; idx < BW_ROWS * N; idx += 256) {
-        const int r = idx / N, c = idx - r * N;
-        ys[r * Nl + c] = (m0 + r < m_end) ? a.dY[(size_t)(m0 + r) * a.ldy + c] : 0.0f;
-      }
+#pragma unroll
+    for (int u = 0; u < PFY; ++u) {
+      int idx = u * 256 + tid;
+      idx = idx < BW_ROWS * YQ ? idx : BW_ROWS * YQ - 1;
+      const int r = idx / YQ, q = idx - r * YQ;
+      int row = m0 + r;
+      row = row < a.M ? row : a.M - 1;
+      pfy[u] = *reinterpret_cast<const float4*>(a.dY + (size_t)row * a.ldy + 4 * (q < N4 ? q : N4 - 1));
     }
-    __syncthreads();
-    if (a.db != nullptr && tid < N) {
-      float cs = 0.0f;
-#pragma unroll 8
-      for (int r = 0; r < BW_ROWS; ++r) cs += ys[r * Nl + tid];
-      colsum += cs;
+  };
+  auto commit = [&](int m0, int b) {    // registers -> LDS buffer b; rows >= m_end and padded columns become zeros
+    float* xs = sm + b * BUF;
+    float* ys = xs + BW_ROWS * Kl;
+#pragma unroll
+    for (int u = 0; u < PFX; ++u) {
+      const int idx = u * 256 + tid;
+      const int r = idx / XQ, q = idx - r * XQ;
+      const bool ok = (m0 + r < m_end) && (q < K4);
+      const float4 v = ok ? pfx[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < BW_ROWS * XQ) *reinterpret_cast<float4*>(xs + r * Kl + 4 * q) = v;
     }
+#pragma unroll
+    for (int u = 0; u < PFY; ++u) {
+      const int idx = u * 256 + tid;
+      const int r = idx / YQ, q = idx - r * YQ;
+      const bool ok = (m0 + r < m_end) && (q < N4) && (idx < BW_ROWS * YQ);
+      const float4 v = ok ? pfy[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < BW_ROWS * YQ) *reinterpret_cast<float4*>(ys + r * Nl + 4 * q) = v;
+      csum[u].x += v.x; csum[u].y += v.y; csum[u].z += v.z; csum[u].w += v.w;
+    }
+  };
+  auto stage_scalar = [&](int m0) {     // unaligned / odd-width fallback: synchronous, buffer 0
+    float* xs = sm;
+    float* ys = xs + BW_ROWS * Kl;
+    for (int idx = tid; idx < BW_ROWS * KT * 16; idx += 256) {
+      const int r = idx / (KT * 16), k = idx - r * (KT * 16);
+      xs[r * Kl + k] = (m0 + r < m_end && k < K) ? a.X[(size_t)(m0 + r) * a.ldx + k] : 0.0f;
+    }
+    for (int idx = tid; idx < BW_ROWS * NT * 16; idx += 256) {
+      const int r = idx / (NT * 16), c = idx - r * (NT * 16);
+      ys[r * Nl + c] = (m0 + r < m_end && c < N) ? a.dY[(size_t)(m0 + r) * a.ldy + c] : 0.0f;
+    }
+  };
+  auto compute = [&](int b) {
+    const float* xs = sm + b * BUF + lq * Kl + li;
+    const float* ys = sm + b * BUF + BW_ROWS * Kl + lq * Nl + li;
 #pragma unroll
     for (int s4 = 0; s4 < BW_ROWS / 4; ++s4) {
-      const int r = s4 * 4 + lq;
-      float bv[NT];
+      float bv[NT], av[KTW];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = (t * 16 + li < N) ? ys[r * Nl + t * 16 + li] : 0.0f;
+      for (int t = 0; t < NT; ++t) bv[t] = ys[s4 * 4 * Nl + t * 16];
 #pragma unroll
       for (int i = 0; i < KTW; ++i) {
-        const int kt = wave + 4 * i;
-        if (kt >= KT) continue;
-        const float av = (kt * 16 + li < K) ? xs[r * Kl + kt * 16 + li] : 0.0f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[i][t], 0, 0, 0);
+        int kt = wave + 4 * i;
+        kt = kt < KT ? kt : KT - 1;                            // surplus waves redo the last tile (never written back)
+        av[i] = xs[s4 * 4 * Kl + kt * 16];
       }
+#pragma unroll
+      for (int i = 0; i < KTW; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[i][t], 0, 0, 0);
     }
+  };
+#define DGPPO_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  float colsum = 0.0f;                  // scalar path only
+  if (vec) {
+    fetch(m_begin);
+    commit(m_begin, 0);
     __syncthreads();
+    int cur = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += BW_ROWS) {
+      fetch(m0 + BW_ROWS);                                     // past m_end on the last round: masked to zeros in commit
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      commit(m0 + BW_ROWS, cur ^ 1);
+      DGPPO_LDS_BARRIER();
+      cur ^= 1;
+    }
+  } else {
+    for (int m0 = m_begin; m0 < m_end; m0 += BW_ROWS) {
+      stage_scalar(m0);
+      __syncthreads();
+      if (a.db != nullptr && tid < N) {
+        const float* ys = sm + BW_ROWS * Kl;
+        float cs = 0.0f;
+#pragma unroll 8
+        for (int r = 0; r < BW_ROWS; ++r) cs += ys[r * Nl + tid];
+        colsum += cs;
+      }
+      compute(0);
+      __syncthreads();
+    }
   }
+#undef DGPPO_LDS_BARRIER
+  float* slab = a.part ? a.part + (size_t)blockIdx.x * a.part_stride : nullptr;
 #pragma unroll
   for (int i = 0; i < KTW; ++i) {
     const int kt = wave + 4 * i;
@@ -383,40 +462,137 @@ __global__ void __launch_bounds__(256) dense_bwd_w_kernel(DenseBwdWArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int krow = kt * 16 + lq * 4 + r;
-        if (krow < K) atomicAdd(a.dW + (size_t)krow * a.ldw + col, acc[i][t][r]);
+        if (krow >= K) continue;
+        if (slab) slab[krow * N + col] = acc[i][t][r];
+        else atomicAdd(a.dW + (size_t)krow * a.ldw + col, acc[i][t][r]);
       }
     }
   }
-  if (a.db != nullptr && tid < N) atomicAdd(a.db + tid, colsum);
+  if (a.db != nullptr) {
+    float cs = colsum;
+    if (vec) {                          // reduce the per-lane column sums through LDS: red[row slot][column]
+      __syncthreads();
+      float* red = sm;
+#pragma unroll
+      for (int u = 0; u < PFY; ++u) {
+        const int idx = u * 256 + tid;
+        const int r = idx / YQ, q = idx - r * YQ;
+        if (idx < BW_ROWS * YQ) *reinterpret_cast<float4*>(red + r * (YQ * 4) + 4 * q) = csum[u];
+      }
+      __syncthreads();
+      cs = 0.0f;
+      if (tid < N) {
+#pragma unroll 8
+        for (int r = 0; r < BW_ROWS; ++r) cs += red[r * (YQ * 4) + tid];
+      }
+    }
+    if (tid < N) {
+      if (slab) slab[K * N + tid] = cs;
+      else atomicAdd(a.db + tid, cs);
+    }
+  }
+}
+
+// Second stage: dW[k][n] += sum_g part[g][k*N + n], db[n] += sum_g part[g][K*N + n].  blockIdx.y splits the slabs so
+// that small outputs still fill the device; the splits meet in at most gridDim.y atomicAdds per element.
+__global__ void __launch_bounds__(256) dense_bwd_w_reduce_kernel(const float* __restrict__ part, int part_stride, int G,
+                                                                 float* __restrict__ dW, int ldw, float* __restrict__ db,
+                                                                 int K, int N) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int E = K * N + (db ? N : 0);
+  if (e >= E) return;
+  const int per = (G + gridDim.y - 1) / gridDim.y;
+  const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = g0;
+  for (; g + 3 < g1; g += 4) {
+    s0 += part[(size_t)g * part_stride + e];
+    s1 += part[(size_t)(g + 1) * part_stride + e];
+    s2 += part[(size_t)(g + 2) * part_stride + e];
+    s3 += part[(size_t)(g + 3) * part_stride + e];
+  }
+  for (; g < g1; ++g) s0 += part[(size_t)g * part_stride + e];
+  const float sum = (s0 + s1) + (s2 + s3);
+  if (g0 >= g1) return;
+  if (e < K * N) {
+    const int k = e / N, n = e - k * N;
+    atomicAdd(dW + (size_t)k * ldw + n, sum);
+  } else {
+    atomicAdd(db + (e - K * N), sum);
+  }
+}
+
+template <int NT, int KT>
+static void launch_bwd_w_kt(DenseBwdWArgs a, hipStream_t s) {
+  constexpr int Kl = (KT & 1) ? KT * 16 : KT * 16 + 16;
+  constexpr int Nl = (NT & 1) ? NT * 16 : NT * 16 + 16;
+  constexpr size_t smem = 2 * sizeof(float) * BW_ROWS * (Kl + Nl);
+  static_assert(smem <= 160 * 1024, "dense_bwd_w tiles exceed the 160 KB LDS of a gfx950 CU");
+  static thread_local int cap = 0;      // resident workgroups on the device, queried once per instantiation
+  if (cap == 0) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bwd_w_kernel<NT, KT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(
+            &dense_bwd_w_kernel<NT, KT>), 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cap = per_cu * cus;
+  }
+  // one resident wave of workgroups; rows per workgroup a multiple of the 32-row tile, at least two tiles
+  int rpb = cdiv(a.M, cap);
+  rpb = ((rpb + BW_ROWS - 1) / BW_ROWS) * BW_ROWS;
+  if (rpb < 2 * BW_ROWS) rpb = 2 * BW_ROWS;
+  // partial slabs: stride rounded to 64 floats; shrink the grid if the scratch buffer cannot hold one slab per workgroup
+  const int stride = ((a.K * a.N + a.N + 63) / 64) * 64;
+  size_t ws_bytes = 0;
+  float* ws = cdiv(a.M, rpb) > 4 ? dgppo_workspace(s, &ws_bytes) : nullptr;
+  if (ws) {
+    const long max_slabs = (long)(ws_bytes / (sizeof(float) * stride));
+    if (max_slabs < 8) ws = nullptr;
+    else if (cdiv(a.M, rpb) > max_slabs) rpb = ((cdiv(a.M, (int)max_slabs) + BW_ROWS - 1) / BW_ROWS) * BW_ROWS;
+  }
+  a.rows_per_block = rpb;
+  a.part = ws;
+  a.part_stride = stride;
+  const int grid = cdiv(a.M, rpb);
+  hipLaunchKernelGGL((dense_bwd_w_kernel<NT, KT>), dim3(grid), dim3(256), smem, s, a);
+  if (ws) {
+    const int E = a.K * a.N + (a.db ? a.N : 0);
+    int splits = cdiv(grid, 32);
+    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+    hipLaunchKernelGGL(dense_bwd_w_reduce_kernel, dim3(cdiv(E, 256), splits), dim3(256), 0, s, ws, stride, grid, a.dW,
+                       a.ldw, a.db, a.K, a.N);
+  }
 }
 
 template <int NT>
-static void launch_bwd_w(const DenseBwdWArgs& a, int grid, hipStream_t s) {
-  const int ktw = cdiv(cdiv(a.K, 16), 4);
-  const size_t smem = sizeof(float) * BW_ROWS * (((a.K + 3) / 4 * 4 + 4) + ((a.N + 3) / 4 * 4 + 4));
-  if (ktw <= 1) hipLaunchKernelGGL((dense_bwd_w_kernel<NT, 1>), dim3(grid), dim3(256), smem, s, a);
-  else if (ktw == 2) hipLaunchKernelGGL((dense_bwd_w_kernel<NT, 2>), dim3(grid), dim3(256), smem, s, a);
-  else if (ktw == 3) hipLaunchKernelGGL((dense_bwd_w_kernel<NT, 3>), dim3(grid), dim3(256), smem, s, a);
-  else hipLaunchKernelGGL((dense_bwd_w_kernel<NT, 4>), dim3(grid), dim3(256), smem, s, a);
+static void launch_bwd_w(const DenseBwdWArgs& a, hipStream_t s) {
+  const int kt = cdiv(a.K, 16);                    // padded-K instantiations: 16,32,48,64,96,128,144,192,256
+  if (kt <= 1) launch_bwd_w_kt<NT, 1>(a, s);
+  else if (kt == 2) launch_bwd_w_kt<NT, 2>(a, s);
+  else if (kt == 3) launch_bwd_w_kt<NT, 3>(a, s);
+  else if (kt == 4) launch_bwd_w_kt<NT, 4>(a, s);
+  else if (kt <= 6) launch_bwd_w_kt<NT, 6>(a, s);
+  else if (kt <= 8) launch_bwd_w_kt<NT, 8>(a, s);
+  else if (kt == 9) launch_bwd_w_kt<NT, 9>(a, s);
+  else if (kt <= 12) launch_bwd_w_kt<NT, 12>(a, s);
+  else launch_bwd_w_kt<NT, 16>(a, s);
 }
 
 int32_t dense_bwd_w_launch(DenseBwdWArgs a, hipStream_t s) {
   DGPPO_REQUIRE(a.M >= 0 && a.K >= 1 && a.N >= 1, "dense_bwd_w: bad shape");
   DGPPO_REQUIRE(a.N <= 192 && a.K <= 256, "dense_bwd_w: N <= 192 and K <= 256 supported (N=%d K=%d)", a.N, a.K);
   DGPPO_REQUIRE(a.X && a.dY && a.dW, "dense_bwd_w: NULL operand");
+  DGPPO_REQUIRE(a.ldx >= a.K && a.ldy >= a.N && a.ldw >= a.N, "dense_bwd_w: leading dimensions too small");
   if (a.M == 0) return 0;
-  // ~1024 workgroups, rows per block a multiple of the 32-row tile
-  int rpb = cdiv(a.M, 1024);
-  rpb = ((rpb + BW_ROWS - 1) / BW_ROWS) * BW_ROWS;
-  if (rpb < 2 * BW_ROWS) rpb = 2 * BW_ROWS;
-  a.rows_per_block = rpb;
-  const int grid = cdiv(a.M, rpb);
   const int nt = cdiv(a.N, 16);
-  if (nt <= 1) launch_bwd_w<1>(a, grid, s);
-  else if (nt <= 2) launch_bwd_w<2>(a, grid, s);
-  else if (nt <= 4) launch_bwd_w<4>(a, grid, s);
-  else if (nt <= 6) launch_bwd_w<6>(a, grid, s);
-  else launch_bwd_w<12>(a, grid, s);
+  if (nt <= 1) launch_bwd_w<1>(a, s);
+  else if (nt <= 2) launch_bwd_w<2>(a, s);
+  else if (nt <= 4) launch_bwd_w<4>(a, s);
+  else if (nt <= 6) launch_bwd_w<6>(a, s);
+  else launch_bwd_w<12>(a, s);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
@@ -430,6 +606,6 @@ extern "C" int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, 
 
 extern "C" int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
                                      float* db, int32_t M, int32_t K, int32_t N, void* stream) {
-  DenseBwdWArgs a{X, ldx, dY, ldy, dW, ldw, db, M, K, N, 0};
+  DenseBwdWArgs a{X, ldx, dY, ldy, dW, ldw, db, M, K, N, 0, nullptr, 0};
   return dense_bwd_w_launch(a, (hipStream_t)stream);
 }

@@ -155,6 +155,10 @@ int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, int32_t ldw
  * (jax.grad at dgppo/algo/informarl.py:377,440 ; dgppo/algo/dgppo.py:316).                          */
 int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
                           float* db, int32_t M, int32_t K, int32_t N, void* stream);
+/* dgppo_dense_bwd_w reduces per-workgroup partial sums through a library-owned scratch buffer: 64 MiB per
+ * (device, stream), hipMalloc'ed on the first call that needs it (so not inside a stream capture) and kept until this
+ * call frees them all.  No reference counterpart (XLA owns its scratch allocations).                        */
+int32_t dgppo_workspace_release(void);
 
 /* Compact record -> per-graph dense features for the GNN: agent node rows Xa [G*n,Fp], other node rows
  * Xo [G*(Ns-n),Fp], per-(agent,slot) edge features [G*n,S,4] and masks [G*n,S] (1/0).  Graph g = e*n_time + t reads
