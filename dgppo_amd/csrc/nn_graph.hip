@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
     for (int it = 0; it < 2; ++it) {
       const int idx = tid + it * 256;
       if (idx < nQp) { const int row = idx / F4, q = idx - row * F4; put4(s_q + row * Fl + 4 * q, vq[it]); }
-      if (idx < nE) { reinterpret_cast<float4*>(s_e)[idx] = ve[it]; s_m[idx] = vm[it]; }
+      if (idx < nE) { const float4 ev = ve[it]; reinterpret_cast<float4*>(s_e)[idx] = make_float4(ev.x, ev.y, ev.z, ev.w); s_m[idx] = vm[it]; }
     }
     // sizes beyond the register budget (large n): plain loops
     for (int idx = tid + 1024; idx < nXp; idx += 256) { const int nd = idx / F4, q = idx - nd * F4; put4(s_x + nd * Fl + 4 * q, (idx < nA) ? xa[idx] : ((idx < nX) ? xo[idx - nA] : z4)); }
@@ -609,6 +609,492 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
     zc[i * a.Kp + c] = (c == kc) ? 1.0f : 0.0f;
   }
   ASTAMP(6);
+}
+
+// ---- persistent forward --------------------------------------------------------------------------------------------
+// Same math as attn_fwd_kernel, restructured around latency: a workgroup walks graphs g, g + gridDim.x, ...; the NEXT
+// graph's operands are fetched from HBM into registers while the current graph runs, and every barrier inside the loop
+// waits for LDS only (a __syncthreads() would also wait for the prefetch and for the output stores).  Gather, softmax
+// and the scatter of P are one phase: the 8 lanes that own an (agent, head) pair read its logits from their row of s_L,
+// then overwrite that same row with P (DS operations of one wave execute in order, no barrier needed).  Stores of a
+// graph's results are issued after the next graph's registers have been committed to LDS, so that the vmcnt wait in
+// commit() covers loads only.  Per graph: 4 LDS barriers, 2 MFMA phases.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define ATT_PX 6    // prefetch capacity in float4 per lane: node rows, qt rows, edge rows
+#define ATT_PQ 3
+#define ATT_PE 2
+#define ATT_ZT 2    // Z tiles per wave kept in registers
+template <int F>
+__global__ void __launch_bounds__(256) attn_fwd_pers_kernel(AttnArgs a) {
+  extern __shared__ float sm[];
+  const Topo& t = a.t;
+  const AttnDims d = attn_dims(t, F, a.H);
+  constexpr int Fl = F + 1, F4 = F / 4, FT = (F + 15) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int n = d.n, S = d.S, Ns = d.Ns, H = d.H, Ll = d.Ll, nH = d.nH, RT = d.RT, CT = d.CT;
+  const int Sp = (S + 3) & ~3, Kp = a.Kp, Wd = F + 4, kc = F + H * Wd;
+  float* s_x = sm;
+  float* s_q = s_x + CT * 16 * Fl;
+  float* s_L = s_q + RT * 16 * Fl;
+  float* s_e = sm + (((CT * 16 * Fl + RT * 16 * Fl + RT * 16 * Ll) + 3) & ~3);   // float4-aligned
+  float* s_m = s_e + n * S * 4;
+  float* s_a = s_m + n * S;               // compact [nH][Sp] attention weights
+  const int nA = n * F4, nX = Ns * F4, nXp = CT * 16 * F4, nQ = nH * F4, nQp = RT * 16 * F4, nE = n * S;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 vx[ATT_PX], vq[ATT_PQ], ve[ATT_PE];
+  float vm[ATT_PE];
+
+  auto fetch = [&](int g, int tid) {             // unconditional clamped loads: all in flight together, nothing waits here
+    const float4* xa = reinterpret_cast<const float4*>(a.Xa + (size_t)g * n * F);
+    const float4* xo = reinterpret_cast<const float4*>(a.Xo + (size_t)g * (Ns - n) * F);
+    const float4* q4 = reinterpret_cast<const float4*>(a.qt + (size_t)g * nH * F);
+    const float4* e4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
+    const float* mk = a.emask + (size_t)g * n * S;
+#pragma unroll
+    for (int it = 0; it < ATT_PX; ++it) {
+      int idx = tid + it * 256;
+      idx = idx < nX ? idx : nX - 1;
+      const float4* p = (idx < nA) ? xa + idx : xo + (idx - nA);
+      vx[it] = *p;
+    }
+#pragma unroll
+    for (int it = 0; it < ATT_PQ; ++it) {
+      int idx = tid + it * 256;
+      idx = idx < nQ ? idx : nQ - 1;
+      vq[it] = q4[idx];
+    }
+#pragma unroll
+    for (int it = 0; it < ATT_PE; ++it) {
+      int idx = tid + it * 256;
+      idx = idx < nE ? idx : nE - 1;
+      ve[it] = e4[idx];
+      vm[it] = mk[idx];
+    }
+  };
+  auto commit = [&](int g, int tid) {            // registers -> LDS (zero padding), plus the parts of zcat that are plain copies
+    float* zc = a.zcat + (size_t)g * n * Kp;
+#pragma unroll
+    for (int it = 0; it < ATT_PX; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < nXp) {
+        const int nd = idx / F4, q = idx - nd * F4;
+        const float4 v = (idx < nX) ? vx[it] : z4;
+        put4(s_x + nd * Fl + 4 * q, v);
+        if (idx < nA) *reinterpret_cast<float4*>(zc + nd * Kp + 4 * q) = v;      // direct x_i part
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ATT_PQ; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < nQp) { const int row = idx / F4, q = idx - row * F4; put4(s_q + row * Fl + 4 * q, (idx < nQ) ? vq[it] : z4); }
+    }
+#pragma unroll
+    for (int it = 0; it < ATT_PE; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < nE) { const float4 ev = ve[it]; reinterpret_cast<float4*>(s_e)[idx] = make_float4(ev.x, ev.y, ev.z, ev.w); s_m[idx] = vm[it]; }
+    }
+    for (int idx = tid; idx < n * (Kp - kc); idx += 256) {                        // constant column and zero padding
+      const int i = idx / (Kp - kc), c = kc + idx - i * (Kp - kc);
+      zc[i * Kp + c] = (c == kc) ? 1.0f : 0.0f;
+    }
+  };
+
+  int g = blockIdx.x;
+  fetch(g, tid);
+  commit(g, tid);
+  __syncthreads();
+  for (; g < a.G; g += gridDim.x) {
+    const int gn = g + gridDim.x;
+    const bool more = gn < a.G;
+    // an opaque copy of the thread index: without it the compiler hoists every address computation of fetch/commit
+    // out of the graph loop and keeps ~70 extra registers live through the MFMA phases
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const bool st = (g == (int)gridDim.x);   // second graph of workgroup 0 (steady state)
+    if (st) ASTAMP(0);
+    fetch(more ? gn : a.G - 1, tid_o);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- L = Qt * Xs^T : tiles dealt round-robin, all F/4 k-steps of a tile fetched in one LDS round trip ----
+    for (int tile = wave; tile < RT * CT; tile += 4) {
+      const int rt = tile / CT, ct = tile - rt * CT;
+      const float* qa = s_q + (rt * 16 + li) * Fl + lq;
+      const float* xb = s_x + (ct * 16 + li) * Fl + lq;
+      float av[F4], bv[F4];
+#pragma unroll
+      for (int u = 0; u < F4; ++u) { av[u] = qa[4 * u]; bv[u] = xb[4 * u]; }
+      f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < F4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_L[(rt * 16 + lq * 4 + r) * Ll + ct * 16 + li] = acc[r];
+    }
+    LDS_BARRIER();
+    if (st) ASTAMP(1);
+    // ---- gather + softmax + edge aggregation + scatter of P, 8 lanes per (agent, head) pair ----
+    float* zc = a.zcat + (size_t)g * n * Kp;
+    float4 ze_out = z4;
+    int ze_off = -1;
+    for (int p0 = 0; p0 < nH; p0 += 32) {
+      const int pair = p0 + (tid >> 3), sub = tid & 7;
+      const bool live = pair < nH;
+      const int i = live ? pair / H : 0, h = live ? pair - (pair / H) * H : 0;
+      float* Lrow = s_L + (live ? pair : 0) * Ll;
+      float l[ATT_SMAX / 8];
+      int nd[ATT_SMAX / 8];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < ATT_SMAX / 8; ++j) {
+        const int sl = sub + 8 * j;
+        const bool ok = live && sl < S;
+        nd[j] = ok ? sender_node(t, i, sl) : 0;
+        const float lv = Lrow[nd[j]];
+        l[j] = (ok && s_m[i * S + (ok ? sl : 0)] != 0.0f) ? lv : -INFINITY;
+        mx = fmaxf(mx, l[j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 8)); mx = fmaxf(mx, __shfl_xor(mx, 2, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+      float den = 0.0f;
+#pragma unroll
+      for (int j = 0; j < ATT_SMAX / 8; ++j) {
+        const float ev = (l[j] == -INFINITY) ? 0.0f : expf(l[j] - mx);
+        l[j] = ev;
+        den += ev;
+      }
+      den += __shfl_xor(den, 1, 8); den += __shfl_xor(den, 2, 8); den += __shfl_xor(den, 4, 8);
+      const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
+      if (live) for (int c = sub; c < CT * 16; c += 8) Lrow[c] = 0.0f;            // own row: logits -> zeros -> P
+      float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+#pragma unroll
+      for (int j = 0; j < ATT_SMAX / 8; ++j) {
+        const int sl = sub + 8 * j;
+        if (live && sl < S) {
+          const float av = l[j] * inv;
+          s_a[pair * Sp + sl] = av;
+          if (av != 0.0f) {   // masked slots may carry 5e5 / NaN edge features: skip, never multiply
+            Lrow[nd[j]] = av;
+            const float4 e = reinterpret_cast<const float4*>(s_e)[i * S + sl];
+            z0 = fmaf(av, e.x, z0); z1 = fmaf(av, e.y, z1); z2 = fmaf(av, e.z, z2); z3 = fmaf(av, e.w, z3);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { z0 += __shfl_xor(z0, o, 8); z1 += __shfl_xor(z1, o, 8); z2 += __shfl_xor(z2, o, 8); z3 += __shfl_xor(z3, o, 8); }
+      if (live && sub == 0) {
+        if (p0 == 0) { ze_out = make_float4(z0, z1, z2, z3); ze_off = i * Kp + F + h * Wd + F; }   // stored after commit
+        else *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + F) = make_float4(z0, z1, z2, z3);
+      }
+    }
+    LDS_BARRIER();
+    if (st) ASTAMP(2);
+    // ---- Zx = P * Xs : <= ATT_ZT tiles per wave, results stay in registers until after the commit ----
+    f32x4g zacc[ATT_ZT];
+#pragma unroll
+    for (int zt = 0; zt < ATT_ZT; ++zt) {
+      zacc[zt] = f32x4g{0.f, 0.f, 0.f, 0.f};
+      const int tile = wave + 4 * zt;
+      if (tile < RT * FT) {
+        const int rt = tile / FT, ft = tile - rt * FT;
+        const float* pa = s_L + (rt * 16 + li) * Ll + lq;
+        const int col = ft * 16 + li;
+        const float* xb = s_x + lq * Fl + (col < F ? col : 0);
+        for (int k0 = 0; k0 < CT * 4; k0 += 8) {                                 // 8 k-steps per LDS round trip
+          float av[8], bv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k4 = (k0 + u < CT * 4) ? k0 + u : CT * 4 - 1;
+            av[u] = pa[4 * k4];
+            bv[u] = xb[4 * k4 * Fl];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool okk = k0 + u < CT * 4;
+            zacc[zt] = __builtin_amdgcn_mfma_f32_16x16x4f32(okk ? av[u] : 0.0f, (okk && col < F) ? bv[u] : 0.0f, zacc[zt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    LDS_BARRIER();                      // every wave is done with s_x / s_q / s_L of graph g
+    if (st) ASTAMP(3);
+    if (more) commit(gn, tid_o);
+    __builtin_amdgcn_sched_barrier(0);
+    if (st) ASTAMP(4);
+    // ---- stores of graph g ----
+    if (ze_off >= 0) *reinterpret_cast<float4*>(zc + ze_off) = ze_out;
+#pragma unroll
+    for (int zt = 0; zt < ATT_ZT; ++zt) {
+      const int tile = wave + 4 * zt;
+      if (tile < RT * FT) {
+        const int rt = tile / FT, ft = tile - rt * FT, col = ft * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rt * 16 + lq * 4 + r;
+          if (row < nH && col < F) { const int i = row / H, h = row - i * H; zc[i * Kp + F + h * Wd + col] = zacc[zt][r]; }
+        }
+      }
+    }
+    for (int idx = tid; idx < n * S * H; idx += 256) {
+      const int h = idx % H, is = idx / H, i = is / S, sl = is - i * S;
+      a.attn[(size_t)g * n * S * H + idx] = s_a[(i * H + h) * Sp + sl];
+    }
+    LDS_BARRIER();
+    if (st) { ASTAMP(5); ASTAMP(6); }
+  }
+}
+
+// ---- one wave per graph --------------------------------------------------------------------------------------------
+// For the graph sizes DGPPO uses (n*H <= 32 query rows, <= 96 nodes) a whole graph fits one wave: there is no
+// workgroup barrier anywhere, the 4 waves of a workgroup run 4 independent graphs and other waves fill the stalls.
+//   * MFMA fragments come straight from global memory in fragment layout.  The sum over features may visit k in any
+//     order as long as A and B agree, so lane (li, lq) takes the F/4 CONTIGUOUS features lq*F/4 .. of row li: a few
+//     16-byte loads per lane instead of strided 4-byte ones.
+//   * only the logit tile lives in LDS: L = Qt Xs^T is written there, the 8 lanes that own an (agent, head) pair read
+//     its logits, and overwrite the row with P in place (DS operations of one wave are ordered), then Zx = P Xs reads
+//     P as the A operand while the B operand (node rows, already in L2) is loaded directly in fragment layout.
+#define ATW_RT 2      // row tiles (n*H <= 32)
+#define ATW_BX 48     // registers for the node fragments of the logit GEMM: CT * F/4 <= 48
+#define ATW_BZ 48     // registers for the node fragments of the aggregation GEMM: 4*CT * ceil(F/16) <= 48
+// CT = ceil(Ns/16) node tiles, NP = ceil(n*H/8) softmax passes of 8 (agent, head) pairs, SJ = ceil(S/8) slots per softmax
+// lane: compile-time, so the kernel is straight-line code and the per-slot mask / edge features can be prefetched into
+// registers.
+template <int F, int CT, int NP, int SJ>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) attn_fwd_wave_kernel(AttnArgs a) {
+  extern __shared__ float sm[];
+  constexpr int FQ = F / 4, FT = (F + 15) / 16, KZ = CT * 4, Ll = CT * 16 + 1, RT = (NP + 1) / 2;   // RT query-row tiles
+  static_assert(CT * FQ <= ATW_BX && KZ * FT <= ATW_BZ && RT <= ATW_RT, "fragments exceed the register budget");
+  const Topo& t = a.t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const int g = blockIdx.x * 4 + wave;
+  if (g >= a.G) return;                                        // no barriers below: a wave may leave on its own
+  const int n = t.n, S = t.S, Ns = t.Ns, H = a.H, nH = n * H, Kp = a.Kp;
+  const int Wd = F + 4, kc = F + H * Wd;
+  const int hmagic = (65536 + H - 1) / H;                      // row / H == (row * hmagic) >> 16 for row * H < 65536
+  float* s_L = sm + wave * (RT * 16 * Ll);
+  ASTAMP(0);
+  const float* Xa = a.Xa + (size_t)g * n * F;
+  const float* Xo = a.Xo + (size_t)g * (Ns - n) * F - (size_t)n * F;   // indexed by node id (>= n)
+  const float* qt = a.qt + (size_t)g * nH * F;
+  float* zc = a.zcat + (size_t)g * n * Kp;
+  auto xrow = [&](int node) -> const float* {                  // rows past Ns are clamped: they only meet zeros of P
+    node = node < Ns ? node : Ns - 1;
+    return (node < n ? Xa : Xo) + (size_t)node * F;
+  };
+  // ---- fragments of the logit GEMM (rows past n*H clamped: those rows of L are cleared before they are used) ----
+  float aq[RT][FQ], bx[CT][FQ];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int row = rt * 16 + li;
+    row = row < nH ? row : nH - 1;
+    const float* p = qt + (size_t)row * F + lq * FQ;
+#pragma unroll
+    for (int u = 0; u < FQ; ++u) aq[rt][u] = p[u];
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float* p = xrow(ct * 16 + li) + lq * FQ;
+#pragma unroll
+    for (int u = 0; u < FQ; ++u) bx[ct][u] = p[u];
+  }
+  // ---- everything else the wave will need from global memory, issued behind the fragments: the x_i rows that are
+  //      copied into zcat, and per softmax lane (8 lanes per (agent, head) pair, NP passes of 8 pairs) the mask and
+  //      edge features of its SJ slots ----
+  const int sub = lane & 7;
+  float4 xcopy = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < n * FQ) xcopy = reinterpret_cast<const float4*>(Xa)[lane];
+  float mkv[NP][SJ];
+  int pi[NP], ph[NP];
+  {
+    const float* mk = a.emask + (size_t)g * n * S;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      int pair = (lane >> 3) + 8 * p;
+      pair = pair < nH ? pair : nH - 1;
+      pi[p] = (pair * hmagic) >> 16;
+      ph[p] = pair - pi[p] * H;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        int sl = sub + 8 * j;
+        sl = sl < S ? sl : S - 1;
+        mkv[p][j] = mk[pi[p] * S + sl];
+      }
+    }
+  }
+  ASTAMP(1);
+  // ---- L = Qt Xs^T, one row tile at a time, its column tiles interleaved (independent accumulators) ----
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    f32x4g acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4g{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < FQ; ++u)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[rt][u], bx[ct][u], acc[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_L[(rt * 16 + lq * 4 + r) * Ll + ct * 16 + li] = acc[ct][r];
+  }
+  ASTAMP(2);
+  // ---- node fragments of the aggregation GEMM: issued now (not earlier: the logit fragments are dead by now), they
+  //      land while the softmax runs ----
+  __builtin_amdgcn_sched_barrier(0);
+  float bz[KZ][FT];
+#pragma unroll
+  for (int k4 = 0; k4 < KZ; ++k4) {
+    const float* p = xrow(k4 * 4 + lq);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) { const int col = ft * 16 + li; bz[k4][ft] = p[col < F ? col : F - 1]; }
+  }
+  float4 efv[NP][SJ];                   // edge features of this lane's slots (consumed at the end of each pass)
+  {
+    const float* ef = a.efeat + (size_t)g * n * S * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        int sl = sub + 8 * j;
+        sl = sl < S ? sl : S - 1;
+        efv[p][j] = reinterpret_cast<const float4*>(ef)[pi[p] * S + sl];
+      }
+  }
+  // the parts of zcat that are plain copies: x_i, the constant column, zero padding
+  if (lane < n * FQ) *reinterpret_cast<float4*>(zc + (lane / FQ) * Kp + 4 * (lane % FQ)) = xcopy;
+  for (int idx = lane + 64; idx < n * FQ; idx += 64)
+    *reinterpret_cast<float4*>(zc + (idx / FQ) * Kp + 4 * (idx % FQ)) = reinterpret_cast<const float4*>(Xa)[idx];
+  {
+    const int wpad = Kp - kc;                                  // >= 1: the constant column, then zeros
+    for (int i = lane; i < n; i += 64)
+      for (int c = 0; c < wpad; ++c) zc[i * Kp + kc + c] = (c == 0) ? 1.0f : 0.0f;
+  }
+  ASTAMP(3);
+  // ---- gather + softmax + edge aggregation + scatter of P ----
+  {
+    float* at = a.attn + (size_t)g * n * S * H;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int pair = (lane >> 3) + 8 * p;
+      const bool live = pair < nH;
+      const int i = pi[p], h = ph[p];
+      float* Lrow = s_L + (live ? pair : 0) * Ll;
+      float l[SJ];
+      int nd[SJ];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const int sl = sub + 8 * j;
+        const bool ok = live && sl < S;
+        nd[j] = ok ? sender_node(t, i, sl) : 0;
+        const float lv = Lrow[nd[j]];
+        l[j] = (ok && mkv[p][j] != 0.0f) ? lv : -INFINITY;
+        mx = fmaxf(mx, l[j]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 8)); mx = fmaxf(mx, __shfl_xor(mx, 2, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+      float den = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const float ev = (l[j] == -INFINITY) ? 0.0f : expf(l[j] - mx);
+        l[j] = ev;
+        den += ev;
+      }
+      den += __shfl_xor(den, 1, 8); den += __shfl_xor(den, 2, 8); den += __shfl_xor(den, 4, 8);
+      const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
+      if (live) {
+#pragma unroll
+        for (int c = 0; c < CT * 2; ++c) Lrow[sub + 8 * c] = 0.0f;   // own row: logits -> zeros -> P
+      }
+      float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const int sl = sub + 8 * j;
+        if (live && sl < S) {
+          const float av = l[j] * inv;
+          at[(i * S + sl) * H + h] = av;
+          if (av != 0.0f) {   // masked slots may carry 5e5 / NaN edge features: skip, never multiply
+            Lrow[nd[j]] = av;
+            const float4 e = efv[p][j];
+            z0 = fmaf(av, e.x, z0); z1 = fmaf(av, e.y, z1); z2 = fmaf(av, e.z, z2); z3 = fmaf(av, e.w, z3);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { z0 += __shfl_xor(z0, o, 8); z1 += __shfl_xor(z1, o, 8); z2 += __shfl_xor(z2, o, 8); z3 += __shfl_xor(z3, o, 8); }
+      if (live && sub == 0) *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + F) = make_float4(z0, z1, z2, z3);
+    }
+  }
+  // rows of the last row tile past n*H still hold logits of clamped query rows: P must be zero there
+  for (int idx = nH * Ll + lane; idx < RT * 16 * Ll; idx += 64) s_L[idx] = 0.0f;
+  ASTAMP(4);
+  // ---- Zx = P Xs: all (row tile, feature tile) accumulators interleaved over the node k-steps ----
+  {
+    f32x4g acc[RT][FT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) acc[rt][ft] = f32x4g{0.f, 0.f, 0.f, 0.f};
+    // columns of P past Ns are zero (cleared, never scattered to), so clamped node rows contribute nothing
+#pragma unroll
+    for (int k0 = 0; k0 < KZ; k0 += 8) {
+      float pa[8][RT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (k0 + u < KZ) pa[u][rt] = s_L[(rt * 16 + li) * Ll + 4 * (k0 + u) + lq];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft)
+            if (k0 + u < KZ) acc[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[u][rt], bz[k0 + u][ft], acc[rt][ft], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + lq * 4 + r;
+        const int i = (row * hmagic) >> 16, h = row - i * H;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          const int col = ft * 16 + li;
+          if (row < nH && col < F) zc[i * Kp + F + h * Wd + col] = acc[rt][ft][r];
+        }
+      }
+  }
+  ASTAMP(5); ASTAMP(6);
+}
+
+// dispatch over the compile-time tile counts; returns false if the shape has no instantiation
+template <int F, int CT, int NP>
+static bool launch_attn_wave_sj(const AttnArgs& a, int SJ, int grid, hipStream_t s) {
+  const size_t smem = sizeof(float) * 4 * ((NP + 1) / 2) * 16 * (CT * 16 + 1);
+  switch (SJ) {
+    case 1: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 1>), dim3(grid), dim3(256), smem, s, a); return true;
+    case 2: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 2>), dim3(grid), dim3(256), smem, s, a); return true;
+    case 3: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 3>), dim3(grid), dim3(256), smem, s, a); return true;
+    case 4: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 4>), dim3(grid), dim3(256), smem, s, a); return true;
+    default: return false;
+  }
+}
+template <int F, int CT>
+static bool launch_attn_wave_np(const AttnArgs& a, int NP, int SJ, int grid, hipStream_t s) {
+  switch (NP) {
+    case 1: return launch_attn_wave_sj<F, CT, 1>(a, SJ, grid, s);
+    case 2: return launch_attn_wave_sj<F, CT, 2>(a, SJ, grid, s);
+    case 3: return launch_attn_wave_sj<F, CT, 3>(a, SJ, grid, s);
+    case 4: return launch_attn_wave_sj<F, CT, 4>(a, SJ, grid, s);
+    default: return false;
+  }
+}
+template <int F>
+static bool launch_attn_wave(const AttnArgs& a, int CT, int NP, int SJ, int grid, hipStream_t s) {
+  constexpr int FQ = F / 4, FT = (F + 15) / 16;
+  constexpr int CTMAX = (ATW_BX / FQ) < (ATW_BZ / (4 * FT)) ? (ATW_BX / FQ) : (ATW_BZ / (4 * FT));
+  switch (CT) {
+#define DGPPO_CASE(C) case C: if constexpr (C <= CTMAX) return launch_attn_wave_np<F, C>(a, NP, SJ, grid, s); else return false;
+    DGPPO_CASE(1) DGPPO_CASE(2) DGPPO_CASE(3) DGPPO_CASE(4) DGPPO_CASE(5) DGPPO_CASE(6)
+#undef DGPPO_CASE
+    default: return false;
+  }
 }
 
 __global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
@@ -784,7 +1270,34 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   DGPPO_REQUIRE(smem <= 64 * 1024, "attn_fwd: graph too large for LDS (%zu B)", smem);
   const AttnDims d = attn_dims(t, F, H);
   const size_t msmem = attn_mfma_smem(d, false);
-  if ((F & 3) == 0 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
+  const bool mfma_ok = (F & 3) == 0 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU");
+  // persistent variant: operands of one graph must fit the prefetch registers, Z tiles the per-wave accumulators
+  const bool pers_ok = mfma_ok && (F == 8 || F == 16 || F == 32 || F == 64) && (Kp & 3) == 0 &&
+                       d.CT * 16 * (F / 4) <= ATT_PX * 256 && d.RT * 16 * (F / 4) <= ATT_PQ * 256 &&
+                       t.n * t.S <= ATT_PE * 256 && d.RT * ((F + 15) / 16) <= 4 * ATT_ZT && !getenv("DGPPO_ATTN_V1");
+  // one wave per graph when the shape has an instantiation (fragments within the register budget)
+  bool launched = false;
+  if (mfma_ok && (Kp & 3) == 0 && t.n * H * H < 65536 && !getenv("DGPPO_ATTN_BLOCK")) {
+    const int grid = (G + 3) / 4;
+    if (F == 8) launched = launch_attn_wave<8>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
+    else if (F == 16) launched = launch_attn_wave<16>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
+    else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
+    else if (F == 64) launched = launch_attn_wave<64>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
+  }
+  if (launched) {
+  } else if (pers_ok) {
+    const void* fn = F == 8 ? (const void*)&attn_fwd_pers_kernel<8> : F == 16 ? (const void*)&attn_fwd_pers_kernel<16>
+                   : F == 32 ? (const void*)&attn_fwd_pers_kernel<32> : (const void*)&attn_fwd_pers_kernel<64>;
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, msmem) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int grid = G < per_cu * cus ? G : per_cu * cus;
+    if (F == 8) hipLaunchKernelGGL(attn_fwd_pers_kernel<8>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
+    else if (F == 16) hipLaunchKernelGGL(attn_fwd_pers_kernel<16>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
+    else if (F == 32) hipLaunchKernelGGL(attn_fwd_pers_kernel<32>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_pers_kernel<64>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
+  } else if (mfma_ok)
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_fwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);

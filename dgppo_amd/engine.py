@@ -13,6 +13,7 @@ import dataclasses
 from typing import Callable, Dict, Optional
 
 import numpy as np
+import os
 import torch
 
 from . import _native as N
@@ -90,8 +91,13 @@ class OptState:
 
 class Engine:
     def __init__(self, cfg: N.EnvCfg, hyper: Hyper, device, T: int = 128,
-                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, prepass_graphs: int = 1 << 16):
+                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, prepass_graphs: int = 1 << 16,
+                 use_graphs: bool = False):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
+        # HIP-graph replay of the launch-bound rollout loop (18 small kernels per env step).  Opt-in because the record
+        # buffers then belong to the engine: a RolloutData stays valid only until the next rollout of the same kind.
+        self.use_graphs = use_graphs and os.environ.get("DGPPO_HIPGRAPH", "1") != "0"
+        self._ro_cache: Dict[tuple, dict] = {}
         self.n_cost = 2
         self.policy = nets.Net("policy", cfg, hyper.actor_gnn_layers, 2, device)
         self.Vl = nets.Net("Vl", cfg, hyper.Vl_gnn_layers, 1, device)
@@ -126,20 +132,9 @@ class Engine:
         f.compute(agent_slab, n * sd, 0, goal, obst, hits_slab, n * cfg.top_k * 2, 0, None, B, 1)
         return f
 
-    def rollout(self, seeds: torch.Tensor, stochastic: bool, noise_seed: int = 0) -> RolloutData:
-        cfg, T = self.cfg, self.T
-        B = int(seeds.shape[0])
-        n = cfg.n_agents
-        ro = RolloutData(cfg, B, T, self.device, stochastic)
-        OE.env_reset(cfg, seeds, ro.agent_tm[0], ro.goal, ro.obst)
-        if ro.has_hits:
-            OE.env_step(cfg, ro.agent_tm[0], None, ro.goal, ro.obst, None, self.ray_cos, self.ray_sin, None, ro.hits_tm[0],
-                        None, None, None)
-        ro.rnn_tm[0].zero_()                                   # init_rnn_state = zeros (informarl.py:115-124)
-        eps = None
-        if stochastic:
-            eps = self.arena.get("ro.eps", T, B * n, 2)
-            OE.randn(noise_seed, 0, eps.view(-1))
+    def _rollout_steps(self, ro: RolloutData, eps, B: int, stochastic: bool):
+        """the T env steps of a rollout: policy forward (GNN + GRU + head) and env.step, all on the current stream."""
+        cfg, T, n = self.cfg, self.T, self.cfg.n_agents
         for t in range(T):
             hits_t = ro.hits_tm[t] if ro.has_hits else None
             feats = self._feats_at("ro", ro.agent_tm[t], hits_t, ro.goal, ro.obst, B)
@@ -152,6 +147,45 @@ class Engine:
                 K.policy_head(act["ms"], None, None, a_t, None, None, n, 1)
             OE.env_step(cfg, ro.agent_tm[t], ro.action_tm[t], ro.goal, ro.obst, hits_t, self.ray_cos, self.ray_sin,
                         ro.agent_tm[t + 1], ro.hits_tm[t + 1] if ro.has_hits else None, ro.reward_tm[t], ro.cost_tm[t], None)
+
+    def rollout(self, seeds: torch.Tensor, stochastic: bool, noise_seed: int = 0) -> RolloutData:
+        cfg, T = self.cfg, self.T
+        B = int(seeds.shape[0])
+        n = cfg.n_agents
+        slot = None
+        if self.use_graphs:
+            # persistent record buffers per (B, kind): eager on the first call, captured on the second, replayed after
+            slot = self._ro_cache.setdefault((B, stochastic), {"ro": None, "graph": None, "gen": -1, "calls": 0})
+            if slot["ro"] is None:
+                slot["ro"] = RolloutData(cfg, B, T, self.device, stochastic)
+            ro = slot["ro"]
+            ro._env_major = False
+        else:
+            ro = RolloutData(cfg, B, T, self.device, stochastic)
+        OE.env_reset(cfg, seeds, ro.agent_tm[0], ro.goal, ro.obst)
+        if ro.has_hits:
+            OE.env_step(cfg, ro.agent_tm[0], None, ro.goal, ro.obst, None, self.ray_cos, self.ray_sin, None, ro.hits_tm[0],
+                        None, None, None)
+        ro.rnn_tm[0].zero_()                                   # init_rnn_state = zeros (informarl.py:115-124)
+        eps = None
+        if stochastic:
+            eps = self.arena.get("ro.eps", T, B * n, 2)
+            OE.randn(noise_seed, 0, eps.view(-1))
+        if slot is None:
+            self._rollout_steps(ro, eps, B, stochastic)
+            return ro
+        slot["calls"] += 1
+        if slot["graph"] is not None and slot["gen"] != self.arena.generation:
+            slot["graph"] = None                               # a scratch buffer moved: the captured pointers are stale
+        if slot["graph"] is None and slot["calls"] >= 2:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._rollout_steps(ro, eps, B, stochastic)
+            slot["graph"], slot["gen"] = graph, self.arena.generation
+        if slot["graph"] is not None:
+            slot["graph"].replay()
+        else:
+            self._rollout_steps(ro, eps, B, stochastic)       # first call: eager (also sizes every scratch buffer)
         return ro
 
     # ------------------------------------------------------------------------------------------------------------------

@@ -78,6 +78,7 @@ class Arena:
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, torch.Tensor] = {}
+        self.generation = 0          # bumped whenever a buffer is (re)allocated: captured HIP graphs check it before replay
 
     def get(self, name: str, *shape, dtype=torch.float32, zero=False) -> torch.Tensor:
         n = int(np.prod(shape))
@@ -85,6 +86,7 @@ class Arena:
         if b is None or b.numel() < n or b.dtype != dtype:
             b = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self.bufs[name] = b
+            self.generation += 1
         v = b[:n].view(*shape)
         if zero:
             v.zero_()

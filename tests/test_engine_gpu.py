@@ -124,3 +124,29 @@ def test_update_targets_and_gradients(cuda, kind, n, n_obs):
         assert k in info and np.isfinite(info[k]), k
     assert abs(info["eval/safe_data"] - wt["safe"]) < 0.05
     assert info["Vl/has_nan"] == 0.0 and float(eng.opt["policy"].state[2]) == B // Eb
+
+
+def test_rollout_hip_graph_replay_is_bit_exact(cuda):
+    """Engine(use_graphs=True): eager first call, captured second call, replayed afterwards — every rollout must equal
+    the eager engine's bit for bit, also after the policy parameters changed in place between calls."""
+    from dgppo_amd import engine as EN
+    B, T_ = 8, 6
+    cfg, ocfg, hp, eng_e, trees = _setup("LidarSpread", 3, 2, B, T_, cuda, 16, 3)
+    eng_g = EN.Engine(cfg, hp, cuda, T=T_, use_graphs=True)
+    for k, net in eng_g.nets.items():
+        net.load_tree(trees[k])
+    for call in range(4):
+        seeds = (torch.arange(1, B + 1, dtype=torch.int64, device=cuda) + 100 * call) * 7919
+        if call == 3:   # in-place parameter update, as the optimiser does it
+            for e in (eng_e, eng_g):
+                e.policy.params.mul_(1.01)
+        for stochastic in (True, False):
+            a = eng_e.rollout(seeds, stochastic, noise_seed=3 + call).finalize()
+            b = eng_g.rollout(seeds, stochastic, noise_seed=3 + call).finalize()
+            for name in ("agent", "hits", "actions", "log_pis", "rnn_states", "rewards", "costs"):
+                x, y = getattr(a, name), getattr(b, name)
+                if x is None:
+                    assert y is None
+                    continue
+                assert torch.equal(x, y), f"call {call} stochastic={stochastic}: {name} differs"
+    assert eng_g._ro_cache[(B, True)]["graph"] is not None and eng_g._ro_cache[(B, False)]["graph"] is not None

@@ -15,4 +15,4 @@ for (F, Kp) in ((8, 48), (32, 144)):
     out = (C.c_ulonglong * 32)()
     N.lib().dgppo_debug_stamps_attn(out)
     st = np.array(out[:7], dtype=np.int64)
-    print("F", F, "fwd phases [stage, L, softmax, P, Z, ze+writes]:", (st[1:] - st[:-1]).tolist(), "total", int(st[6] - st[0]))
+    print("F", F, "fwd phases (wave kernel: [issue frag loads, L mfma+write, bz issue+copies, softmax, Z mfma+stores, -])", (st[1:] - st[:-1]).tolist(), "total", int(st[6] - st[0]))
