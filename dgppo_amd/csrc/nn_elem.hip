@@ -107,7 +107,6 @@ extern "C" int32_t dgppo_ln_relu_bwd(const float* x, const float* y, const float
 //   r = sig(gi_r + h Whr)  z = sig(gi_z + h Whz)  n = tanh(gi_n + r * (h Whn + bhn))  h' = (1 - z) n + z h
 // ---------------------------------------------------------------------------------------------------------------------
 #define GRU_H 64
-#define GRU_SEQ 64   // sequences per workgroup
 #define GRU_WL 193   // padded LDS row of Wh
 #define GRU_HL 65    // padded LDS row of h
 
@@ -132,186 +131,240 @@ __device__ inline size_t gru_row(const GruArgs& a, int s, int tau) {
 }
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// SEQ = sequences per workgroup (64: one 16-row tile per wave x all 12 column tiles; 16: one row tile shared by the 4
-// waves, 3 column tiles each — 4x shorter MFMA chain per step for small / latency-bound launches).
-template <int SEQ>
+#define GRU_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Persistent workgroups walk tiles of RB = 16*RTW sequences.  Wave w owns hidden columns 16w..16w+15 of all three gates
+// (column tiles w, w+4, w+8 of h Wh), and its Wh fragments (16 k-steps x 3 tiles = 48 registers) stay resident for the
+// whole launch.  The h tile is double-buffered in LDS: one LDS-only barrier per step.  The gate inputs gi of a step are
+// requested before its MFMAs and consumed after them; the next tile's h0 rows are requested at the start of a tile.
+template <int RTW>
 __global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
   extern __shared__ float sm[];
-  float* s_w = sm;                       // [64][GRU_WL]
-  float* s_h = s_w + GRU_H * GRU_WL;     // [SEQ][GRU_HL]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lq = lane >> 4;
-  constexpr int NTW = (SEQ == 64) ? 12 : 3;            // column tiles per wave
-  const int rt = (SEQ == 64) ? wave : 0;               // row tile of this wave
-  const int ct0 = (SEQ == 64) ? 0 : wave;              // first column tile; tiles ct0 + 4*j  (gate j of columns 16*wave..)
-  const int s0 = blockIdx.x * SEQ;
-  for (int idx = tid; idx < GRU_H * 192; idx += 256) {
-    const int k = idx / 192, c = idx - k * 192;
-    s_w[k * GRU_WL + c] = a.Wh[idx];
-  }
-  for (int idx = tid; idx < SEQ * GRU_H; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    const int s = s0 + r;
-    s_h[r * GRU_HL + c] = (a.h0 != nullptr && s < a.n_seq) ? a.h0[(size_t)s * GRU_H + c] : 0.0f;
-  }
+  constexpr int RB = 16 * RTW;
+  constexpr int HSLOT = RB * 16 / 256 > 0 ? RB * 16 / 256 : 1;   // float4 slots of an h tile per lane (RB*16 / 256)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int c = w * 16 + li;                                     // hidden column of this lane
+  float breg[16][3];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) breg[kk][t] = a.Wh[(size_t)(kk * 4 + lq) * 192 + t * 64 + c];
+  const float bn = a.bhn[c];
+  const int n_tiles = (a.n_seq + RB - 1) / RB;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float hpf[HSLOT][4];                   // (plain floats: a float4 array captured by the lambdas ends up in scratch)
+  auto fetch_h0 = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < HSLOT; ++u) {
+      int idx = u * 256 + tid;
+      idx = idx < RB * 16 ? idx : RB * 16 - 1;
+      const int r = idx >> 4, q = idx & 15;
+      int s = tile * RB + r;
+      s = s < a.n_seq ? s : a.n_seq - 1;
+      float4 v = z4;
+      if (a.h0 != nullptr) v = reinterpret_cast<const float4*>(a.h0 + (size_t)s * GRU_H)[q];
+      hpf[u][0] = v.x; hpf[u][1] = v.y; hpf[u][2] = v.z; hpf[u][3] = v.w;
+    }
+  };
+  auto commit_h0 = [&](float* dst) {
+#pragma unroll
+    for (int u = 0; u < HSLOT; ++u) {
+      const int idx = u * 256 + tid, r = idx >> 4, q = idx & 15;
+      if (idx < RB * 16) { float* d = dst + r * GRU_HL + 4 * q; d[0] = hpf[u][0]; d[1] = hpf[u][1]; d[2] = hpf[u][2]; d[3] = hpf[u][3]; }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < n_tiles) { fetch_h0(tile); commit_h0(sm); }
   __syncthreads();
-  // this lane's output elements: rows rl = rt*16 + lq*4 + r (r < 4); columns c = tt*16 + li with
-  //   SEQ 64: tt = 0..3 (tiles tt, tt+4, tt+8 = the r|z|n gates of column block tt);  SEQ 16: tt = wave only
-  constexpr int NC = (SEQ == 64) ? 4 : 1;
-  for (int tau = 0; tau < a.T; ++tau) {
-    // gate inputs of this step: issued before the MFMA loop so that their latency hides behind it
-    float gr[NC][4], gz[NC][4], gn[NC][4];
-    size_t rowi[4];
-    bool ok[4];
+  int cur = 0;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int s0 = tile * RB;
+    const int nxt = tile + gridDim.x;
+    if (nxt < n_tiles) fetch_h0(nxt);
+    // rows of this lane's output elements at tau = 0 (row(tau) = row0 + tau * n_inner), clamped for loads
+    int row0[RTW][4];
+    bool ok[RTW][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int s = s0 + rt * 16 + lq * 4 + r;
-      ok[r] = s < a.n_seq;
-      rowi[r] = ok[r] ? gru_row(a, s, tau) : 0;
-#pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        const int c = ((SEQ == 64) ? q : wave) * 16 + li;
-        const float* g = a.gi + rowi[r] * 192;
-        gr[q][r] = ok[r] ? g[c] : 0.0f; gz[q][r] = ok[r] ? g[64 + c] : 0.0f; gn[q][r] = ok[r] ? g[128 + c] : 0.0f;
-      }
-    }
-    f32x4 acc[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* hrow = s_h + (rt * 16 + li) * GRU_HL;
-#pragma unroll 4
-    for (int k0 = 0; k0 < GRU_H; k0 += 4) {
-      const float av = hrow[k0 + lq];
-      const float* wrow = s_w + (k0 + lq) * GRU_WL + li;
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const int ct = (SEQ == 64) ? t : (ct0 + 4 * t);     // SEQ 16: tiles wave, wave+4, wave+8 = r|z|n of column block `wave`
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[ct * 16], acc[t], 0, 0, 0);
-      }
-    }
-    __syncthreads();  // every wave has read s_h before anyone overwrites it
-#pragma unroll
-    for (int q = 0; q < NC; ++q) {
-      const int cb = (SEQ == 64) ? q : wave;
-      const int c = cb * 16 + li;
-      const float bn = a.bhn[c];
+    for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (!ok[r]) continue;
-        const int rl = rt * 16 + lq * 4 + r;
-        const float ar = (SEQ == 64) ? acc[q][r] : acc[0][r];
-        const float az = (SEQ == 64) ? acc[q + 4][r] : acc[1][r];
-        const float an = (SEQ == 64) ? acc[q + 8][r] : acc[2][r];
-        const float hp = s_h[rl * GRU_HL + c];
-        const float rg = sigmoidf_(gr[q][r] + ar);
-        const float zg = sigmoidf_(gz[q][r] + az);
-        const float hn = an + bn;
-        const float ng = tanhf(gn[q][r] + rg * hn);
-        const float hnew = (1.0f - zg) * ng + zg * hp;
-        a.hs[rowi[r] * GRU_H + c] = hnew;
-        if (a.hprev != nullptr) a.hprev[rowi[r] * GRU_H + c] = hp;
-        if (a.gates != nullptr) {
-          float* gs = a.gates + rowi[r] * 256;
-          gs[c] = rg; gs[64 + c] = zg; gs[128 + c] = ng; gs[192 + c] = hn;
-        }
-        s_h[rl * GRU_HL + c] = hnew;
+        int s = s0 + rt * 16 + lq * 4 + r;
+        ok[rt][r] = s < a.n_seq;
+        s = ok[rt][r] ? s : a.n_seq - 1;
+        const int grp = s / a.n_inner;
+        row0[rt][r] = grp * a.T * a.n_inner + (s - grp * a.n_inner);
       }
+    for (int tau = 0; tau < a.T; ++tau) {
+      const float* hs_cur = sm + cur * (RB * GRU_HL);
+      float* hs_nxt = sm + (cur ^ 1) * (RB * GRU_HL);
+      float g[RTW][4][3];
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* gp = a.gi + (size_t)(row0[rt][r] + tau * a.n_inner) * 192 + c;
+          g[rt][r][0] = gp[0]; g[rt][r][1] = gp[64]; g[rt][r][2] = gp[128];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      float areg[RTW][16];
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = hs_cur[(rt * 16 + li) * GRU_HL + kk * 4 + lq];
+      f32x4 acc[RTW][3];
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], breg[kk][t], acc[rt][t], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = rt * 16 + lq * 4 + r;
+          const float hp = hs_cur[rl * GRU_HL + c];
+          const float rg = sigmoidf_(g[rt][r][0] + acc[rt][0][r]);
+          const float zg = sigmoidf_(g[rt][r][1] + acc[rt][1][r]);
+          const float hn = acc[rt][2][r] + bn;
+          const float ng = tanhf(g[rt][r][2] + rg * hn);
+          const float hnew = (1.0f - zg) * ng + zg * hp;
+          hs_nxt[rl * GRU_HL + c] = hnew;
+          if (ok[rt][r]) {
+            const size_t row = (size_t)(row0[rt][r] + tau * a.n_inner);
+            a.hs[row * GRU_H + c] = hnew;
+            if (a.hprev != nullptr) a.hprev[row * GRU_H + c] = hp;
+            if (a.gates != nullptr) {
+              float* gs = a.gates + row * 256;
+              gs[c] = rg; gs[64 + c] = zg; gs[128 + c] = ng; gs[192 + c] = hn;
+            }
+          }
+        }
+      GRU_LDS_BARRIER();
+      cur ^= 1;
     }
-    __syncthreads();
+    if (nxt < n_tiles) {
+      commit_h0(sm + cur * (RB * GRU_HL));
+      GRU_LDS_BARRIER();
+    }
   }
 }
 
-// BPTT: walks tau = T-1 .. 0 carrying dh; the recurrent product dh_prev += dgh * Wh^T runs on the matrix cores.
-// The saved gates / hprev / upstream gradient of step tau-1 are fetched while step tau's product runs.
-template <int SEQ>
+// BPTT: walks tau = T-1 .. 0.  Each lane owns the same (sequence row, hidden column) elements as in the forward (the
+// MFMA output layout), so the carried dh lives in registers: dh_prev = dh * z + (dgh Wh^T), the product running on the
+// matrix cores with the Wh^T fragments (48 k-steps x 1 column tile) resident in registers.  dgh tiles are
+// double-buffered in LDS: one LDS-only barrier per step.  The saved gates / hprev / upstream gradient of step tau-1 are
+// requested while step tau's product runs.
+template <int RTW>
 __global__ void __launch_bounds__(256) gru_bwd_kernel(GruArgs a) {
   extern __shared__ float sm[];
-  float* s_w = sm;                        // [64][GRU_WL]   Wh
-  float* s_g = s_w + GRU_H * GRU_WL;      // [SEQ][GRU_WL]  dgh of this step
-  float* s_dh = s_g + SEQ * GRU_WL;       // [SEQ][GRU_HL]  carried dh
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lq = lane >> 4;
-  const int s0 = blockIdx.x * SEQ;
-  constexpr int EPT = SEQ * GRU_H / 256;  // elements per thread in the elementwise phase (16 or 4)
-  for (int idx = tid; idx < GRU_H * 192; idx += 256) {
-    const int k = idx / 192, c = idx - k * 192;
-    s_w[k * GRU_WL + c] = a.Wh[idx];
+  constexpr int RB = 16 * RTW;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int c = w * 16 + li;
+  float breg[48];                       // B[k][j = c] = Wh[c][k]
+#pragma unroll
+  for (int kk = 0; kk < 48; ++kk) breg[kk] = a.Wh[(size_t)c * 192 + kk * 4 + lq];
+  const int n_tiles = (a.n_seq + RB - 1) / RB;
+  int cur = 0;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int s0 = tile * RB;
+    int row0[RTW][4];
+    bool ok[RTW][4];
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int s = s0 + rt * 16 + lq * 4 + r;
+        ok[rt][r] = s < a.n_seq;
+        s = ok[rt][r] ? s : a.n_seq - 1;
+        const int grp = s / a.n_inner;
+        row0[rt][r] = grp * a.T * a.n_inner + (s - grp * a.n_inner);
+      }
+    float rg[RTW][4], zg[RTW][4], ng[RTW][4], hn[RTW][4], hp[RTW][4], du[RTW][4], dh[RTW][4];
+    auto fetch = [&](int tau) {
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t row = (size_t)(row0[rt][r] + tau * a.n_inner);
+          const float* gs = a.gates + row * 256 + c;
+          rg[rt][r] = gs[0]; zg[rt][r] = gs[64]; ng[rt][r] = gs[128]; hn[rt][r] = gs[192];
+          hp[rt][r] = a.hprev[row * GRU_H + c];
+          du[rt][r] = a.dhs[row * GRU_H + c];
+        }
+    };
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[rt][r] = 0.0f;
+    fetch(a.T - 1);
+    for (int tau = a.T - 1; tau >= 0; --tau) {
+      float* s_g = sm + cur * (RB * GRU_WL);
+      // phase A: gate gradients of this lane's elements
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = rt * 16 + lq * 4 + r;
+          const float d = ok[rt][r] ? dh[rt][r] + du[rt][r] : 0.0f;
+          const float dz = d * (hp[rt][r] - ng[rt][r]);
+          const float dn = d * (1.0f - zg[rt][r]);
+          const float dan = dn * (1.0f - ng[rt][r] * ng[rt][r]);
+          const float dhn = dan * rg[rt][r];
+          const float dar = dan * hn[rt][r] * rg[rt][r] * (1.0f - rg[rt][r]);
+          const float daz = dz * zg[rt][r] * (1.0f - zg[rt][r]);
+          dh[rt][r] = d * zg[rt][r];
+          s_g[rl * GRU_WL + c] = dar;
+          s_g[rl * GRU_WL + 64 + c] = daz;
+          s_g[rl * GRU_WL + 128 + c] = dhn;
+          if (ok[rt][r]) {
+            const size_t row = (size_t)(row0[rt][r] + tau * a.n_inner);
+            float* o = a.dgi + row * 192 + c;
+            o[0] = dar; o[64] = daz; o[128] = dan;
+            float* p = a.dgh + row * 192 + c;
+            p[0] = dar; p[64] = daz; p[128] = dhn;
+          }
+        }
+      GRU_LDS_BARRIER();
+      if (tau > 0) fetch(tau - 1);          // in flight during the product below
+      __builtin_amdgcn_sched_barrier(0);
+      // phase B: dh_prev[row, c] += sum_k dgh[row, k] * Wh[c, k]
+      f32x4 acc[RTW];
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k0 = 0; k0 < 48; k0 += 16) {
+        float areg[RTW][16];
+#pragma unroll
+        for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+          for (int u = 0; u < 16; ++u) areg[rt][u] = s_g[(rt * 16 + li) * GRU_WL + (k0 + u) * 4 + lq];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int rt = 0; rt < RTW; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][u], breg[k0 + u], acc[rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[rt][r] += acc[rt][r];
+      cur ^= 1;                             // the next step writes the other dgh buffer: no second barrier needed
+    }
+    GRU_LDS_BARRIER();                      // (the tile after this one may start on the buffer another wave still reads)
   }
-  for (int idx = tid; idx < SEQ * GRU_HL; idx += 256) s_dh[idx] = 0.0f;
-  float rg[EPT], zg[EPT], ng[EPT], hn[EPT], hp[EPT], du[EPT];
-  auto fetch = [&](int tau) {
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int idx = tid + e * 256, rl = idx >> 6, c = idx & 63;
-      const int sq = s0 + rl;
-      if (sq < a.n_seq) {
-        const size_t row = gru_row(a, sq, tau);
-        const float* gs = a.gates + row * 256;
-        rg[e] = gs[c]; zg[e] = gs[64 + c]; ng[e] = gs[128 + c]; hn[e] = gs[192 + c];
-        hp[e] = a.hprev[row * GRU_H + c];
-        du[e] = a.dhs[row * GRU_H + c];
-      } else {
-        rg[e] = zg[e] = ng[e] = hn[e] = hp[e] = du[e] = 0.0f;
-      }
-    }
-  };
-  fetch(a.T - 1);
-  __syncthreads();
-  for (int tau = a.T - 1; tau >= 0; --tau) {
-    // phase A: gate gradients, elementwise (operands already in registers)
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int idx = tid + e * 256, rl = idx >> 6, c = idx & 63;
-      const int sq = s0 + rl;
-      float dar = 0.f, daz = 0.f, dan = 0.f, dhn = 0.f, dhz = 0.f;
-      if (sq < a.n_seq) {
-        const size_t row = gru_row(a, sq, tau);
-        const float dh = s_dh[rl * GRU_HL + c] + du[e];
-        const float dz = dh * (hp[e] - ng[e]);
-        const float dn = dh * (1.0f - zg[e]);
-        dan = dn * (1.0f - ng[e] * ng[e]);
-        dhn = dan * rg[e];
-        dar = dan * hn[e] * rg[e] * (1.0f - rg[e]);
-        daz = dz * zg[e] * (1.0f - zg[e]);
-        dhz = dh * zg[e];
-        float* o = a.dgi + row * 192;
-        o[c] = dar; o[64 + c] = daz; o[128 + c] = dan;
-        float* p = a.dgh + row * 192;
-        p[c] = dar; p[64 + c] = daz; p[128 + c] = dhn;
-      }
-      s_g[rl * GRU_WL + c] = dar;
-      s_g[rl * GRU_WL + 64 + c] = daz;
-      s_g[rl * GRU_WL + 128 + c] = dhn;
-      s_dh[rl * GRU_HL + c] = dhz;
-    }
-    __syncthreads();
-    if (tau > 0) fetch(tau - 1);          // in flight during the product below
-    // phase B: dh_prev[row, c] += sum_k dgh[row, k] * Wh[c, k]
-    if constexpr (SEQ == 64) {
-      f32x4 acc[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* grow = s_g + (wave * 16 + li) * GRU_WL;
-#pragma unroll 4
-      for (int k0 = 0; k0 < 192; k0 += 4) {
-        const float av = grow[k0 + lq];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_w[(t * 16 + li) * GRU_WL + k0 + lq], acc[t], 0, 0, 0);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_dh[(wave * 16 + lq * 4 + r) * GRU_HL + t * 16 + li] += acc[t][r];
-    } else {   // one 16-row tile, wave w owns output columns 16w .. 16w+15
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* grow = s_g + li * GRU_WL;
-#pragma unroll 8
-      for (int k0 = 0; k0 < 192; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[k0 + lq], s_w[(wave * 16 + li) * GRU_WL + k0 + lq], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_dh[(lq * 4 + r) * GRU_HL + wave * 16 + li] += acc[r];
-    }
-    __syncthreads();
-  }
+}
+
+// resident workgroups of a kernel on the current device (occupancy x CUs)
+static int gru_resident(const void* fn, size_t smem) {
+  int per_cu = 0, dev = 0, cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  return per_cu * cus;
 }
 
 static int32_t gru_check(const GruArgs& a) {
@@ -329,12 +382,19 @@ extern "C" int32_t dgppo_gru_fwd(const float* gi, const float* Wh, const float* 
   if (rc) return rc;
   if (n_seq == 0) return 0;
   DGPPO_REQUIRE(gi && Wh && bhn && hs, "gru_fwd: NULL operand");
-  if (cdiv(n_seq, 64) < 192) {   // fewer than ~3/4 of a wave of 64-sequence workgroups: shorten the per-step chain instead
-    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)16 * GRU_HL);
-    hipLaunchKernelGGL(gru_fwd_kernel<16>, dim3(cdiv(n_seq, 16)), dim3(256), smem, (hipStream_t)stream, a);
+  // 32-sequence tiles when there are enough of them to fill the device, otherwise 16 (half the MFMA chain per step)
+  if (cdiv(n_seq, 32) >= 512) {
+    const size_t smem = sizeof(float) * 2 * 32 * GRU_HL;
+    static thread_local int cap = 0;
+    if (cap == 0) cap = gru_resident(reinterpret_cast<const void*>(&gru_fwd_kernel<2>), smem);
+    const int tiles = cdiv(n_seq, 32);
+    hipLaunchKernelGGL(gru_fwd_kernel<2>, dim3(tiles < cap ? tiles : cap), dim3(256), smem, (hipStream_t)stream, a);
   } else {
-    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)64 * GRU_HL);
-    hipLaunchKernelGGL(gru_fwd_kernel<64>, dim3(cdiv(n_seq, 64)), dim3(256), smem, (hipStream_t)stream, a);
+    const size_t smem = sizeof(float) * 2 * 16 * GRU_HL;
+    static thread_local int cap = 0;
+    if (cap == 0) cap = gru_resident(reinterpret_cast<const void*>(&gru_fwd_kernel<1>), smem);
+    const int tiles = cdiv(n_seq, 16);
+    hipLaunchKernelGGL(gru_fwd_kernel<1>, dim3(tiles < cap ? tiles : cap), dim3(256), smem, (hipStream_t)stream, a);
   }
   DGPPO_LAUNCH_CHECK();
   return 0;
@@ -349,12 +409,18 @@ extern "C" int32_t dgppo_gru_bwd(const float* dhs, const float* Wh, const float*
   if (rc) return rc;
   if (n_seq == 0) return 0;
   DGPPO_REQUIRE(dhs && Wh && hprev && gates && dgi && dgh, "gru_bwd: NULL operand");
-  if (cdiv(n_seq, 64) < 192) {
-    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)16 * GRU_WL + (size_t)16 * GRU_HL);
-    hipLaunchKernelGGL(gru_bwd_kernel<16>, dim3(cdiv(n_seq, 16)), dim3(256), smem, (hipStream_t)stream, a);
+  if (cdiv(n_seq, 32) >= 512) {
+    const size_t smem = sizeof(float) * 2 * 32 * GRU_WL;
+    static thread_local int cap = 0;
+    if (cap == 0) cap = gru_resident(reinterpret_cast<const void*>(&gru_bwd_kernel<2>), smem);
+    const int tiles = cdiv(n_seq, 32);
+    hipLaunchKernelGGL(gru_bwd_kernel<2>, dim3(tiles < cap ? tiles : cap), dim3(256), smem, (hipStream_t)stream, a);
   } else {
-    const size_t smem = sizeof(float) * ((size_t)GRU_H * GRU_WL + (size_t)64 * GRU_WL + (size_t)64 * GRU_HL);
-    hipLaunchKernelGGL(gru_bwd_kernel<64>, dim3(cdiv(n_seq, 64)), dim3(256), smem, (hipStream_t)stream, a);
+    const size_t smem = sizeof(float) * 2 * 16 * GRU_WL;
+    static thread_local int cap = 0;
+    if (cap == 0) cap = gru_resident(reinterpret_cast<const void*>(&gru_bwd_kernel<1>), smem);
+    const int tiles = cdiv(n_seq, 16);
+    hipLaunchKernelGGL(gru_bwd_kernel<1>, dim3(tiles < cap ? tiles : cap), dim3(256), smem, (hipStream_t)stream, a);
   }
   DGPPO_LAUNCH_CHECK();
   return 0;
