@@ -1,0 +1,208 @@
+// Fused row pipelines (fp32 MFMA): chains of row-local layers that the reference runs back to back on the same rows,
+// executed by one persistent kernel so that the activations between them never leave the CU.
+//
+// Reference arithmetic replaced (file:line relative to /root/reference):
+//   MLP block (Dense -> LayerNorm -> ReLU) x 2     dgppo/nn/mlp.py:17-29   (hid_sizes (64, 64), act_final=True)
+//   GRUCell input projection  x W_i + b_i          dgppo/nn/rnn.py:14-30   (flax GRUCell: dense_i of the r|z|n gates)
+//   as composed by                                  dgppo/algo/module/policy.py:191-212, value.py:58-80
+#include "common.h"
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+#define FZ_H 64            // hidden width of every layer in the chain
+#define FZ_HL 65           // LDS row stride (odd: conflict-free A-fragment reads)
+#define FZ_RB 32           // rows per tile (2 row tiles of 16 per wave)
+#define FZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+struct MlpGiArgs {
+  const float* X; int ldx; int M;
+  const float *W1, *b1, *g1, *be1, *W2, *b2, *g2, *be2, *Wi, *bi;
+  float *p1, *y1, *st1, *p2, *y2, *st2;   // saved for the backward (all NULL in inference)
+  float* gi;                              // [M, 192]
+};
+
+// One workgroup = 4 waves; wave w owns hidden columns 16w..16w+15 of the 64-wide layers and column tiles w, w+4, w+8 of
+// the 192-wide gate projection.  All weight fragments of the wave (16 + 16 + 48 k-step registers) are loaded once and
+// stay resident while the workgroup walks 32-row tiles; the next tile's rows are requested while the current one
+// computes.  LayerNorm statistics: 16-lane shuffle reduction inside the wave, 4-way exchange through LDS.  Four LDS-only
+// barriers per tile.
+__global__ void __launch_bounds__(256) mlp_gi_fwd_kernel(MlpGiArgs a) {
+  extern __shared__ float sm[];
+  float* s_x = sm;                              // [RB][HL]  input rows
+  float* s_y1 = s_x + FZ_RB * FZ_HL;            // [RB][HL]  relu(LN(x W1 + b1))
+  float* s_y2 = s_y1 + FZ_RB * FZ_HL;           // [RB][HL]  relu(LN(y1 W2 + b2))
+  float* s_red = s_y2 + FZ_RB * FZ_HL;          // [RB][8]   per-row (sum, sum of squares) of each of the 4 waves
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int c = w * 16 + li;
+  float w1[16], w2[16], wi[16][3];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = kk * 4 + lq;
+    w1[kk] = a.W1[k * FZ_H + c];
+    w2[kk] = a.W2[k * FZ_H + c];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wi[kk][t] = a.Wi[k * 192 + t * 64 + c];
+  }
+  const float b1 = a.b1[c], g1 = a.g1[c], e1 = a.be1[c], b2 = a.b2[c], g2 = a.g2[c], e2 = a.be2[c];
+  const float bi0 = a.bi[c], bi1 = a.bi[64 + c], bi2 = a.bi[128 + c];
+  const int n_tiles = (a.M + FZ_RB - 1) / FZ_RB;
+  const bool vec = ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+  float xpf[2][4];
+  auto fetch = [&](int tile) {            // 32 rows x 16 float4 = 512 slots, 2 per lane; rows clamped
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = u * 256 + tid, r = idx >> 4, q = idx & 15;
+      int row = tile * FZ_RB + r;
+      row = row < a.M ? row : a.M - 1;
+      const float* p = a.X + (size_t)row * a.ldx + 4 * q;
+      if (vec) { const float4 v = *reinterpret_cast<const float4*>(p); xpf[u][0] = v.x; xpf[u][1] = v.y; xpf[u][2] = v.z; xpf[u][3] = v.w; }
+      else { xpf[u][0] = p[0]; xpf[u][1] = p[1]; xpf[u][2] = p[2]; xpf[u][3] = p[3]; }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = u * 256 + tid, r = idx >> 4, q = idx & 15;
+      float* d = s_x + r * FZ_HL + 4 * q;
+      d[0] = xpf[u][0]; d[1] = xpf[u][1]; d[2] = xpf[u][2]; d[3] = xpf[u][3];
+    }
+  };
+  // y = relu(LN(v)) for this lane's 8 elements (2 row tiles x 4 rows, column c); v is overwritten
+  auto ln_relu = [&](float (&v)[2][4], float g, float e, float* s_out, float* y_out, float* st_out, int row0) {
+    // partial sums over the wave's 16 columns
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = v[rt][r], q = v[rt][r] * v[rt][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 16); q += __shfl_xor(q, o, 16); }
+        if (li == 0) { float* d = s_red + (rt * 16 + lq * 4 + r) * 8 + 2 * w; d[0] = s; d[1] = q; }
+      }
+    FZ_LDS_BARRIER();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = rt * 16 + lq * 4 + r;
+        const float4 p0 = *reinterpret_cast<const float4*>(s_red + rl * 8);
+        const float4 p1 = *reinterpret_cast<const float4*>(s_red + rl * 8 + 4);
+        const float mean = ((p0.x + p0.z) + (p1.x + p1.z)) * (1.0f / 64.0f);
+        const float mean2 = ((p0.y + p0.w) + (p1.y + p1.w)) * (1.0f / 64.0f);
+        const float var = fmaxf(mean2 - mean * mean, 0.0f);
+        const float rstd = rsqrtf(var + 1e-6f);
+        const float y = fmaxf((v[rt][r] - mean) * rstd * g + e, 0.0f);
+        s_out[rl * FZ_HL + c] = y;
+        const int row = row0 + rl;
+        if (y_out != nullptr && row < a.M) {
+          y_out[(size_t)row * FZ_H + c] = y;
+          if (c == 0) { st_out[(size_t)row * 2] = mean; st_out[(size_t)row * 2 + 1] = rstd; }
+        }
+      }
+    FZ_LDS_BARRIER();
+  };
+  int tile = blockIdx.x;
+  if (tile < n_tiles) { fetch(tile); commit(); }
+  __syncthreads();
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int row0 = tile * FZ_RB;
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < n_tiles;
+    if (more) fetch(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    float areg[2][16];
+    f32x4 acc[2];
+    float v[2][4];
+    // ---- layer 1 ----
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_x[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], w1[kk], acc[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[rt][r] = acc[rt][r] + b1;
+        const int row = row0 + rt * 16 + lq * 4 + r;
+        if (a.p1 != nullptr && row < a.M) a.p1[(size_t)row * FZ_H + c] = v[rt][r];
+      }
+    // (the first barrier inside ln_relu also retires every read of s_x: the next tile's rows may be committed after it)
+    ln_relu(v, g1, e1, s_y1, a.y1, a.st1, row0);
+    if (more) commit();
+    // ---- layer 2 ----
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_y1[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], w2[kk], acc[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[rt][r] = acc[rt][r] + b2;
+        const int row = row0 + rt * 16 + lq * 4 + r;
+        if (a.p2 != nullptr && row < a.M) a.p2[(size_t)row * FZ_H + c] = v[rt][r];
+      }
+    ln_relu(v, g2, e2, s_y2, a.y2, a.st2, row0);
+    // ---- gate projection ----
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_y2[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    f32x4 ag[2][3];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) ag[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ag[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], wi[kk][t], ag[rt][t], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + rt * 16 + lq * 4 + r;
+        if (row < a.M) {
+          float* o = a.gi + (size_t)row * 192 + c;
+          o[0] = ag[rt][0][r] + bi0; o[64] = ag[rt][1][r] + bi1; o[128] = ag[rt][2][r] + bi2;
+        }
+      }
+  }
+}
+
+extern "C" int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1, const float* b1, const float* g1,
+                                    const float* be1, const float* W2, const float* b2, const float* g2, const float* be2,
+                                    const float* Wi, const float* bi, float* p1, float* y1, float* st1, float* p2, float* y2,
+                                    float* st2, float* gi, int32_t M, void* stream) {
+  DGPPO_REQUIRE(M >= 0 && ldx >= FZ_H, "mlp_gi_fwd: bad shape M=%d ldx=%d", M, ldx);
+  DGPPO_REQUIRE(X && W1 && b1 && g1 && be1 && W2 && b2 && g2 && be2 && Wi && bi && gi, "mlp_gi_fwd: NULL operand");
+  const bool save = p1 || y1 || st1 || p2 || y2 || st2;
+  DGPPO_REQUIRE(!save || (p1 && y1 && st1 && p2 && y2 && st2), "mlp_gi_fwd: the saved activations are all-or-none");
+  if (M == 0) return 0;
+  MlpGiArgs a{X, ldx, M, W1, b1, g1, be1, W2, b2, g2, be2, Wi, bi, p1, y1, st1, p2, y2, st2, gi};
+  const size_t smem = sizeof(float) * (3 * FZ_RB * FZ_HL + FZ_RB * 8);
+  static thread_local int cap = 0;
+  if (cap == 0) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&mlp_gi_fwd_kernel), 256, smem) !=
+            hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cap = per_cu * cus;
+  }
+  const int tiles = (M + FZ_RB - 1) / FZ_RB;
+  hipLaunchKernelGGL(mlp_gi_fwd_kernel, dim3(tiles < cap ? tiles : cap), dim3(256), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}

@@ -199,16 +199,15 @@ class Net:
         else:
             x, Rh, n_inner = Xa, R, n
         act["Rh"], act["n_inner"], act["mlp_in"] = Rh, n_inner, x
-        for i in (1, 2):
-            pre = A.get(f"{tag}.p{i}", Rh, HID)
-            K.dense_fwd(x, self.p(f"mlp.W{i}"), self.p(f"mlp.b{i}"), pre)
-            y = A.get(f"{tag}.y{i}", Rh, HID)
-            st = A.get(f"{tag}.st{i}", Rh, 2)
-            K.ln_relu_fwd(pre, self.p(f"mlp.g{i}"), self.p(f"mlp.be{i}"), y, st)
-            act[f"p{i}"], act[f"y{i}"], act[f"st{i}"] = pre, y, st
-            x = y
+        # MLP trunk (2 x Dense -> LayerNorm -> ReLU) + GRU input projection: one fused kernel (nn_fused.hip)
         gi = A.get(f"{tag}.gi", Rh, 3 * HID)
-        K.dense_fwd(x, self.p("gru.Wi"), self.p("gru.bi"), gi)
+        saves = None
+        if train:
+            saves = tuple(A.get(f"{tag}.{nm}{i}", Rh, w) for i in (1, 2) for nm, w in (("p", HID), ("y", HID), ("st", 2)))
+            for i in (1, 2):
+                act[f"p{i}"], act[f"y{i}"], act[f"st{i}"] = saves[3 * (i - 1):3 * i]
+        K.mlp_gi_fwd(x, self.p("mlp.W1"), self.p("mlp.b1"), self.p("mlp.g1"), self.p("mlp.be1"), self.p("mlp.W2"),
+                     self.p("mlp.b2"), self.p("mlp.g2"), self.p("mlp.be2"), self.p("gru.Wi"), self.p("gru.bi"), gi, saves)
         hs = hs_out if hs_out is not None else A.get(f"{tag}.hs", Rh, HID)
         hprev = A.get(f"{tag}.hprev", Rh, HID) if train else None
         gates = A.get(f"{tag}.gates", Rh, 4 * HID) if train else None

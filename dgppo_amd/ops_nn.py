@@ -43,6 +43,25 @@ def dense_fwd(X, W, bias, Y, act: int = 0, accumulate: bool = False, trans_w: bo
     N.check(rc, "dgppo_dense_fwd")
 
 
+def mlp_gi_fwd(X, W1, b1, g1, be1, W2, b2, g2, be2, Wi, bi, gi, saves=None):
+    """gi = relu(LN(relu(LN(X W1 + b1)) W2 + b2)) Wi + bi in one kernel; saves = (p1, y1, st1, p2, y2, st2) or None."""
+    xp, ldx, M, K = _mat(X, "X")
+    if K != 64:
+        raise ValueError(f"mlp_gi_fwd: X must be [M, 64], got {tuple(X.shape)}")
+    for t, shp, nm in ((W1, (64, 64), "W1"), (W2, (64, 64), "W2"), (Wi, (64, 192), "Wi"), (b1, (64,), "b1"), (g1, (64,), "g1"),
+                       (be1, (64,), "be1"), (b2, (64,), "b2"), (g2, (64,), "g2"), (be2, (64,), "be2"), (bi, (192,), "bi"),
+                       (gi, (M, 192), "gi")):
+        N.expect_shape(t, shp, nm)
+    sv = [None] * 6
+    if saves is not None:
+        for t, shp, nm in zip(saves, ((M, 64), (M, 64), (M, 2), (M, 64), (M, 64), (M, 2)), ("p1", "y1", "st1", "p2", "y2", "st2")):
+            N.expect_shape(t, shp, nm)
+        sv = list(saves)
+    rc = N.lib().dgppo_mlp_gi_fwd(xp, ldx, _p(W1), _p(b1), _p(g1), _p(be1), _p(W2), _p(b2), _p(g2), _p(be2), _p(Wi), _p(bi),
+                                  *[_p(t) for t in sv], _p(gi), M, N.stream_ptr())
+    N.check(rc, "dgppo_mlp_gi_fwd")
+
+
 def dense_bwd_w(X, dY, dW, db=None):
     """dW += X.T @ dY ; db += dY.sum(0)"""
     xp, ldx, M, K = _mat(X, "X")

@@ -62,6 +62,45 @@ def test_dense_bwd_w(cuda, M, K, N):
     _close(db, dY.double().sum(0), 3e-6 * math.sqrt(M), "db")
 
 
+@pytest.mark.parametrize("M,save,strided", [(1, True, False), (33, False, False), (1000, True, True), (40000, True, False)])
+def test_mlp_gi_fused(cuda, M, save, strided):
+    """fused Dense->LN->ReLU->Dense->LN->ReLU->Dense(192) against the plain torch fp32 composition (mlp.py:17-29,
+    rnn.py:14-30); ragged M (not a multiple of the 32-row tile), strided input, with and without the saved activations."""
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M)
+    Xfull = torch.randn(M, 80, generator=g)
+    X = Xfull[:, 8:72] if strided else Xfull[:, :64].contiguous()
+    P = {k: torch.randn(*shp, generator=g) * sc for k, shp, sc in (
+        ("W1", (64, 64), 0.2), ("b1", (64,), 0.1), ("g1", (64,), 1.0), ("be1", (64,), 0.1), ("W2", (64, 64), 0.2),
+        ("b2", (64,), 0.1), ("g2", (64,), 1.0), ("be2", (64,), 0.1), ("Wi", (64, 192), 0.2), ("bi", (192,), 0.1))}
+
+    def ln(v, gam, bet):   # flax LayerNorm: fast variance, eps 1e-6
+        mean = v.mean(-1, keepdim=True)
+        var = ((v * v).mean(-1, keepdim=True) - mean * mean).clamp_min(0.0)
+        rstd = torch.rsqrt(var + 1e-6)
+        return (v - mean) * rstd * gam + bet, mean, rstd
+
+    p1 = X @ P["W1"] + P["b1"]
+    o1, m1, r1 = ln(p1, P["g1"], P["be1"])
+    y1 = torch.relu(o1)
+    p2 = y1 @ P["W2"] + P["b2"]
+    o2, m2, r2 = ln(p2, P["g2"], P["be2"])
+    y2 = torch.relu(o2)
+    gi_want = y2 @ P["Wi"] + P["bi"]
+    d = {k: v.to(cuda) for k, v in P.items()}
+    Xd = Xfull.to(cuda)[:, 8:72] if strided else X.to(cuda)
+    gi = torch.full((M, 192), float("nan"), device=cuda)
+    saves = None
+    if save:
+        saves = tuple(torch.full((M, w), float("nan"), device=cuda) for w in (64, 64, 2, 64, 64, 2))
+    K_.mlp_gi_fwd(Xd, d["W1"], d["b1"], d["g1"], d["be1"], d["W2"], d["b2"], d["g2"], d["be2"], d["Wi"], d["bi"], gi, saves)
+    _close(gi, gi_want, 2e-5, "gi")
+    if save:
+        for got, want, nm in zip(saves, (p1, y1, torch.cat([m1, r1], 1), p2, y2, torch.cat([m2, r2], 1)),
+                                 ("p1", "y1", "st1", "p2", "y2", "st2")):
+            _close(got, want, 2e-5, nm)
+
+
 def test_ln_relu(cuda):
     from dgppo_amd import ops_nn as K_
     g = torch.Generator().manual_seed(0)
