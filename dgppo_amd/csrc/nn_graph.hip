@@ -1063,34 +1063,272 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   ASTAMP(5); ASTAMP(6);
 }
 
-// dispatch over the compile-time tile counts; returns false if the shape has no instantiation
-template <int F, int CT, int NP>
-static bool launch_attn_wave_sj(const AttnArgs& a, int SJ, int grid, hipStream_t s) {
-  const size_t smem = sizeof(float) * 4 * ((NP + 1) / 2) * 16 * (CT * 16 + 1);
-  switch (SJ) {
-    case 1: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 1>), dim3(grid), dim3(256), smem, s, a); return true;
-    case 2: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 2>), dim3(grid), dim3(256), smem, s, a); return true;
-    case 3: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 3>), dim3(grid), dim3(256), smem, s, a); return true;
-    case 4: hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, 4>), dim3(grid), dim3(256), smem, s, a); return true;
-    default: return false;
+// ---- backward, one wave per graph ----------------------------------------------------------------------------------
+// Same layout rules as attn_fwd_wave_kernel.  The wave's LDS tile [RT*16][Ll] is used three times in sequence:
+//   1. dA = dZx Xs^T (dense), read back at the slots by the 8 lanes that own an (agent, head) pair, which compute the
+//      softmax backward dl = a (dA + dze.e - sum a (dA + dze.e)) in registers;
+//   2. the tile is overwritten with P (own rows, in place) and dXs += P^T dZx runs on the matrix cores;
+//   3. the tile is overwritten with dL and dQt = dL Xs, dXs += dL^T Qt run.
+// DS operations of a wave execute in order, so none of these hand-overs needs a barrier.  The dXs accumulators
+// (CT x ceil(F/16) tiles) stay in registers across 2 and 3.
+template <int F, int CT, int NP, int SJ>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) attn_bwd_wave_kernel(AttnArgs a) {
+  extern __shared__ float sm[];
+  constexpr int FQ = F / 4, FT = (F + 15) / 16, KZ = CT * 4, Ll = CT * 16 + 1, RT = (NP + 1) / 2, KP = RT * 4;
+  const Topo& t = a.t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+  const int g = blockIdx.x * 4 + wave;
+  if (g >= a.G) return;
+  const int n = t.n, S = t.S, Ns = t.Ns, H = a.H, nH = n * H, Kp = a.Kp;
+  const int Wd = F + 4;
+  const int hmagic = (65536 + H - 1) / H;
+  float* s_T = sm + wave * (RT * 16 * Ll);
+  const float* Xa = a.Xa + (size_t)g * n * F;
+  const float* Xo = a.Xo + (size_t)g * (Ns - n) * F - (size_t)n * F;
+  const float* qt = a.qt + (size_t)g * nH * F;
+  const float* dzc = a.dzcat + (size_t)g * n * Kp;
+  const bool want_dx = a.dXa != nullptr;
+  auto xrow = [&](int node) -> const float* {
+    node = node < Ns ? node : Ns - 1;
+    return (node < n ? Xa : Xo) + (size_t)node * F;
+  };
+  auto dzrow = [&](int pair) -> const float* {                 // dZx row of an (agent, head) pair inside dzcat (clamped)
+    pair = pair < nH ? pair : nH - 1;
+    const int i = (pair * hmagic) >> 16, h = pair - i * H;
+    return dzc + i * Kp + F + h * Wd;
+  };
+  // ---- fragments of dA = dZx Xs^T (k-permuted: lane (li, lq) takes features lq*F/4 .. of its row) ----
+  float adz[RT][FQ], bx[CT][FQ];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const float* p = dzrow(rt * 16 + li) + lq * FQ;
+#pragma unroll
+    for (int u = 0; u < FQ; ++u) adz[rt][u] = p[u];
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float* p = xrow(ct * 16 + li) + lq * FQ;
+#pragma unroll
+    for (int u = 0; u < FQ; ++u) bx[ct][u] = p[u];
+  }
+  // ---- per softmax lane: attention weights, edge features and the edge part of dZ for its slots ----
+  const int sub = lane & 7;
+  float av[NP][SJ], ed[NP][SJ];
+  int pi[NP], ph[NP];
+  {
+    const float* ef = a.efeat + (size_t)g * n * S * 4;
+    const float* at = a.attn + (size_t)g * n * S * H;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      int pair = (lane >> 3) + 8 * p;
+      const bool live = pair < nH;
+      pair = live ? pair : nH - 1;
+      pi[p] = (pair * hmagic) >> 16;
+      ph[p] = pair - pi[p] * H;
+      const float4 dze = *reinterpret_cast<const float4*>(dzc + pi[p] * Kp + F + ph[p] * Wd + F);
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        int sl = sub + 8 * j;
+        const bool ok = live && sl < S;
+        sl = sl < S ? sl : S - 1;
+        const float w = at[(pi[p] * S + sl) * H + ph[p]];
+        av[p][j] = ok ? w : 0.0f;
+        const float4 e = reinterpret_cast<const float4*>(ef)[pi[p] * S + sl];
+        // masked slots (a == 0) may carry 5e5 / NaN edge features: never multiply them
+        ed[p][j] = (ok && w != 0.0f) ? fmaf(dze.x, e.x, fmaf(dze.y, e.y, fmaf(dze.z, e.z, dze.w * e.w))) : 0.0f;
+      }
+    }
+  }
+  // ---- dA (dense) -> LDS tile ----
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    f32x4g acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4g{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < FQ; ++u)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(adz[rt][u], bx[ct][u], acc[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_T[(rt * 16 + lq * 4 + r) * Ll + ct * 16 + li] = acc[ct][r];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- fragments needed later, requested now: dZx and Qt as B operands (k = pair), Xs as B operand (k = node) ----
+  float bdz[KP][FT], bq[KP][FT], bz[KZ][FT];
+#pragma unroll
+  for (int k4 = 0; k4 < KP; ++k4) {
+    const int pair = k4 * 4 + lq;
+    const float* pz = dzrow(pair);
+    const float* pq = qt + (size_t)(pair < nH ? pair : nH - 1) * F;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      const int col = ft * 16 + li, cc = col < F ? col : F - 1;
+      bdz[k4][ft] = want_dx ? pz[cc] : 0.0f;
+      bq[k4][ft] = want_dx ? pq[cc] : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int k4 = 0; k4 < KZ; ++k4) {
+    const float* p = xrow(k4 * 4 + lq);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) { const int col = ft * 16 + li; bz[k4][ft] = p[col < F ? col : F - 1]; }
+  }
+  // ---- softmax backward in registers; the tile becomes P ----
+  float dl[NP][SJ];
+  int nd[NP][SJ];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int pair = (lane >> 3) + 8 * p;
+    const bool live = pair < nH;
+    float* Trow = s_T + (live ? pair : 0) * Ll;
+    float dot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) {
+      const int sl = sub + 8 * j;
+      nd[p][j] = (live && sl < S) ? sender_node(t, pi[p], sl) : 0;
+      const float dA = (av[p][j] != 0.0f) ? Trow[nd[p][j]] + ed[p][j] : 0.0f;
+      dl[p][j] = dA;
+      dot = fmaf(av[p][j], dA, dot);
+    }
+    dot += __shfl_xor(dot, 1, 8); dot += __shfl_xor(dot, 2, 8); dot += __shfl_xor(dot, 4, 8);
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) dl[p][j] = av[p][j] * (dl[p][j] - dot);
+    if (live) {
+#pragma unroll
+      for (int cc = 0; cc < CT * 2; ++cc) Trow[sub + 8 * cc] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) if (av[p][j] != 0.0f) Trow[nd[p][j]] = av[p][j];
+    }
+  }
+  // rows past n*H hold dA of clamped rows: they must be zero in every later use of the tile
+  for (int idx = nH * Ll + lane; idx < RT * 16 * Ll; idx += 64) s_T[idx] = 0.0f;
+  // ---- dXs += P^T dZx ----
+  f32x4g dxacc[CT][FT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) dxacc[ct][ft] = f32x4g{0.f, 0.f, 0.f, 0.f};
+  if (want_dx) {
+#pragma unroll
+    for (int k4 = 0; k4 < KP; ++k4) {
+      float pa[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) pa[ct] = s_T[(k4 * 4 + lq) * Ll + ct * 16 + li];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) dxacc[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ct], bdz[k4][ft], dxacc[ct][ft], 0, 0, 0);
+    }
+  }
+  // ---- the tile becomes dL ----
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int pair = (lane >> 3) + 8 * p;
+    if (pair < nH) {
+      float* Trow = s_T + pair * Ll;
+#pragma unroll
+      for (int cc = 0; cc < CT * 2; ++cc) Trow[sub + 8 * cc] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) if (dl[p][j] != 0.0f) Trow[nd[p][j]] = dl[p][j];
+    }
+  }
+  // ---- dQt = dL Xs ----
+  {
+    f32x4g acc[RT][FT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) acc[rt][ft] = f32x4g{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < KZ; k0 += 8) {
+      float pa[8][RT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          if (k0 + u < KZ) pa[u][rt] = s_T[(rt * 16 + li) * Ll + 4 * (k0 + u) + lq];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft)
+            if (k0 + u < KZ) acc[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[u][rt], bz[k0 + u][ft], acc[rt][ft], 0, 0, 0);
+    }
+    float* dq = a.dqt + (size_t)g * nH * F;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + lq * 4 + r;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          const int col = ft * 16 + li;
+          if (row < nH && col < F) dq[row * F + col] = acc[rt][ft][r];
+        }
+      }
+  }
+  // ---- dXs += dL^T Qt, then the stores (+ the direct x_i part of dzcat for agents) ----
+  if (want_dx) {
+#pragma unroll
+    for (int k4 = 0; k4 < KP; ++k4) {
+      float pa[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) pa[ct] = s_T[(k4 * 4 + lq) * Ll + ct * 16 + li];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) dxacc[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ct], bq[k4][ft], dxacc[ct][ft], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = ct * 16 + lq * 4 + r;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          const int f = ft * 16 + li;
+          if (node >= Ns || f >= F) continue;
+          if (node < n) a.dXa[((size_t)g * n + node) * F + f] = dxacc[ct][ft][r] + dzc[node * Kp + f];
+          else if (a.dXo != nullptr) a.dXo[((size_t)g * (Ns - n) + (node - n)) * F + f] = dxacc[ct][ft][r];
+        }
+      }
   }
 }
+
+// dispatch over the compile-time tile counts; returns false if the shape has no instantiation
+template <int F, int CT, int NP>
+static bool launch_attn_wave_sj(const AttnArgs& a, int SJ, int grid, hipStream_t s, bool bwd) {
+  const size_t smem = sizeof(float) * 4 * ((NP + 1) / 2) * 16 * (CT * 16 + 1);
+#define DGPPO_SJ(J)                                                                                              \
+  case J:                                                                                                        \
+    if (bwd) hipLaunchKernelGGL((attn_bwd_wave_kernel<F, CT, NP, J>), dim3(grid), dim3(256), smem, s, a);        \
+    else hipLaunchKernelGGL((attn_fwd_wave_kernel<F, CT, NP, J>), dim3(grid), dim3(256), smem, s, a);            \
+    return true;
+  switch (SJ) {
+    DGPPO_SJ(1) DGPPO_SJ(2) DGPPO_SJ(3) DGPPO_SJ(4)
+    default: return false;
+  }
+#undef DGPPO_SJ
+}
 template <int F, int CT>
-static bool launch_attn_wave_np(const AttnArgs& a, int NP, int SJ, int grid, hipStream_t s) {
+static bool launch_attn_wave_np(const AttnArgs& a, int NP, int SJ, int grid, hipStream_t s, bool bwd) {
   switch (NP) {
-    case 1: return launch_attn_wave_sj<F, CT, 1>(a, SJ, grid, s);
-    case 2: return launch_attn_wave_sj<F, CT, 2>(a, SJ, grid, s);
-    case 3: return launch_attn_wave_sj<F, CT, 3>(a, SJ, grid, s);
-    case 4: return launch_attn_wave_sj<F, CT, 4>(a, SJ, grid, s);
+    case 1: return launch_attn_wave_sj<F, CT, 1>(a, SJ, grid, s, bwd);
+    case 2: return launch_attn_wave_sj<F, CT, 2>(a, SJ, grid, s, bwd);
+    case 3: return launch_attn_wave_sj<F, CT, 3>(a, SJ, grid, s, bwd);
+    case 4: return launch_attn_wave_sj<F, CT, 4>(a, SJ, grid, s, bwd);
     default: return false;
   }
 }
 template <int F>
-static bool launch_attn_wave(const AttnArgs& a, int CT, int NP, int SJ, int grid, hipStream_t s) {
+static bool launch_attn_wave(const AttnArgs& a, int CT, int NP, int SJ, int grid, hipStream_t s, bool bwd = false) {
   constexpr int FQ = F / 4, FT = (F + 15) / 16;
   constexpr int CTMAX = (ATW_BX / FQ) < (ATW_BZ / (4 * FT)) ? (ATW_BX / FQ) : (ATW_BZ / (4 * FT));
   switch (CT) {
-#define DGPPO_CASE(C) case C: if constexpr (C <= CTMAX) return launch_attn_wave_np<F, C>(a, NP, SJ, grid, s); else return false;
+#define DGPPO_CASE(C) case C: if constexpr (C <= CTMAX) return launch_attn_wave_np<F, C>(a, NP, SJ, grid, s, bwd); else return false;
     DGPPO_CASE(1) DGPPO_CASE(2) DGPPO_CASE(3) DGPPO_CASE(4) DGPPO_CASE(5) DGPPO_CASE(6)
 #undef DGPPO_CASE
     default: return false;
@@ -1322,8 +1560,20 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   DGPPO_REQUIRE(smem <= 64 * 1024, "attn_bwd: graph too large for LDS (%zu B)", smem);
   const AttnDims d = attn_dims(t, F, H);
   const size_t msmem = attn_mfma_smem(d, true);
+  // one wave per graph when the shape has an instantiation (same conditions as the forward)
+  bool launched = false;
+  if ((F & 3) == 0 && t.S <= 64 && (Kp & 3) == 0 && t.n * H * H < 65536 && !getenv("DGPPO_ATTN_VALU") &&
+      !getenv("DGPPO_ATTN_BLOCK")) {
+    const int grid = (G + 3) / 4, NP = (d.nH + 7) / 8, SJ = (t.S + 7) / 8;
+    if (F == 8) launched = launch_attn_wave<8>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
+    else if (F == 16) launched = launch_attn_wave<16>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
+    else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
+    else if (F == 64) launched = launch_attn_wave<64>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
+  }
+  if (launched) {
+  }
   // narrow layers (F = 8) are pure latency: there the VALU kernel's shorter dependency chain wins (measured)
-  if ((F & 3) == 0 && F >= 16 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
+  else if ((F & 3) == 0 && F >= 16 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(attn_bwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
