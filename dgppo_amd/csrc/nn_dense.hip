@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
           if (c + kk < KS) areg[r][kk] = xs[r * 16 * Kl + (c + kk) * 4];
+      __builtin_amdgcn_sched_barrier(0);          // one LDS round trip for the chunk, then the MFMAs back to back
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk)
 #pragma unroll

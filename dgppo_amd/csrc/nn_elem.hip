@@ -19,26 +19,41 @@ __device__ inline float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm(64) + ReLU: one wave per row (lane = column)
+// LayerNorm(64) + ReLU: four rows per wave — the 16 lanes of a DPP row own one matrix row, 4 consecutive columns each
+// (one float4).  Row sums = 3 in-lane adds + 4 DPP steps that never leave the VALU (a 64-lane __shfl_xor reduction costs
+// 6 LDS-crossbar round trips per sum).
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ inline float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+
 __global__ void __launch_bounds__(256) ln_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y,
                                                           float* __restrict__ stats, int M) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nw = (gridDim.x * blockDim.x) >> 6;
-  const float g = gamma[lane], b = beta[lane];
-  for (int row = wave; row < M; row += nw) {
-    const float v = x[(size_t)row * 64 + lane];
-    const float mean = wave_sum(v) * (1.0f / 64.0f);
-    const float mean2 = wave_sum(v * v) * (1.0f / 64.0f);
+  const float4 g = reinterpret_cast<const float4*>(gamma)[li], b = reinterpret_cast<const float4*>(beta)[li];
+  for (int row0 = wave * 4; row0 < M; row0 += nw * 4) {
+    const int row = row0 + lq;
+    const bool ok = row < M;
+    const float4 v = reinterpret_cast<const float4*>(x)[(size_t)(ok ? row : M - 1) * 16 + li];
+    const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
+    const float mean2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 64.0f);
     const float var = fmaxf(mean2 - mean * mean, 0.0f);
     const float rstd = rsqrtf(var + 1e-6f);
-    const float o = (v - mean) * rstd * g + b;
-    y[(size_t)row * 64 + lane] = fmaxf(o, 0.0f);
-    if (stats != nullptr && lane == 0) {
-      stats[(size_t)row * 2] = mean;
-      stats[(size_t)row * 2 + 1] = rstd;
+    float4 o;
+    o.x = fmaxf((v.x - mean) * rstd * g.x + b.x, 0.0f);
+    o.y = fmaxf((v.y - mean) * rstd * g.y + b.y, 0.0f);
+    o.z = fmaxf((v.z - mean) * rstd * g.z + b.z, 0.0f);
+    o.w = fmaxf((v.w - mean) * rstd * g.w + b.w, 0.0f);
+    if (ok) {
+      reinterpret_cast<float4*>(y)[(size_t)row * 16 + li] = o;
+      if (stats != nullptr && li == 0) reinterpret_cast<float2*>(stats)[row] = make_float2(mean, rstd);
     }
   }
 }
@@ -48,31 +63,48 @@ __global__ void __launch_bounds__(256) ln_relu_bwd_kernel(const float* __restric
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ dy, float* __restrict__ dx,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int M) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nw = (gridDim.x * blockDim.x) >> 6;
-  const float g = gamma[lane];
-  float dg = 0.0f, db = 0.0f;
-  for (int row = wave; row < M; row += nw) {
-    const size_t o = (size_t)row * 64 + lane;
-    const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
-    const float xhat = (x[o] - mean) * rstd;
-    const float dyl = (y[o] > 0.0f) ? dy[o] : 0.0f;
-    dg += dyl * xhat;
-    db += dyl;
-    const float dxh = dyl * g;
-    const float m1 = wave_sum(dxh) * (1.0f / 64.0f);
-    const float m2 = wave_sum(dxh * xhat) * (1.0f / 64.0f);
-    dx[o] = rstd * (dxh - m1 - xhat * m2);
+  const float4 g = reinterpret_cast<const float4*>(gamma)[li];
+  float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int row0 = wave * 4; row0 < M; row0 += nw * 4) {
+    const int row = row0 + lq;
+    const bool ok = row < M;
+    const size_t o = (size_t)(ok ? row : M - 1) * 16 + li;
+    const float4 xv = reinterpret_cast<const float4*>(x)[o], yv = reinterpret_cast<const float4*>(y)[o];
+    const float4 dv = reinterpret_cast<const float4*>(dy)[o];
+    const float2 st = reinterpret_cast<const float2*>(stats)[ok ? row : M - 1];
+    const float mean = st.x, rstd = st.y;
+    const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
+    const float dl[4] = {(ok && yv.x > 0.0f) ? dv.x : 0.0f, (ok && yv.y > 0.0f) ? dv.y : 0.0f,
+                         (ok && yv.z > 0.0f) ? dv.z : 0.0f, (ok && yv.w > 0.0f) ? dv.w : 0.0f};
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    float dxh[4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      dg[q] += dl[q] * xh[q];
+      db[q] += dl[q];
+      dxh[q] = dl[q] * gg[q];
+      s1 += dxh[q];
+      s2 += dxh[q] * xh[q];
+    }
+    const float m1 = row16_sum(s1) * (1.0f / 64.0f), m2 = row16_sum(s2) * (1.0f / 64.0f);
+    if (ok)
+      reinterpret_cast<float4*>(dx)[o] = make_float4(rstd * (dxh[0] - m1 - xh[0] * m2), rstd * (dxh[1] - m1 - xh[1] * m2),
+                                                     rstd * (dxh[2] - m1 - xh[2] * m2), rstd * (dxh[3] - m1 - xh[3] * m2));
   }
-  // per-workgroup reduction of the 4 waves' partial sums, then one atomic per column
-  __shared__ float red[2][4][64];
-  red[0][threadIdx.x >> 6][lane] = dg;
-  red[1][threadIdx.x >> 6][lane] = db;
+  // per-workgroup reduction of the 16 (wave, row group) partial sums, then one atomic per column
+  __shared__ float red[2][16][64];
+  const int slot = (threadIdx.x >> 6) * 4 + lq;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { red[0][slot][li * 4 + q] = dg[q]; red[1][slot][li * 4 + q] = db[q]; }
   __syncthreads();
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6;
-    const float v = red[which][0][lane] + red[which][1][lane] + red[which][2][lane] + red[which][3][lane];
+    float v = 0.0f;
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx) v += red[which][sidx][lane];
     atomicAdd((which ? dbeta : dgamma) + lane, v);
   }
 }
@@ -82,7 +114,7 @@ extern "C" int32_t dgppo_ln_relu_fwd(const float* x, const float* gamma, const f
   DGPPO_REQUIRE(M >= 0, "ln_relu_fwd: M < 0");
   if (M == 0) return 0;
   DGPPO_REQUIRE(x && gamma && beta && y, "ln_relu_fwd: NULL operand");
-  const int grid = min(cdiv(M, 4), 2048);
+  const int grid = min(cdiv(M, 16), 2048);
   hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, stats, M);
   DGPPO_LAUNCH_CHECK();
   return 0;
@@ -93,7 +125,7 @@ extern "C" int32_t dgppo_ln_relu_bwd(const float* x, const float* y, const float
   DGPPO_REQUIRE(M >= 0, "ln_relu_bwd: M < 0");
   if (M == 0) return 0;
   DGPPO_REQUIRE(x && y && stats && gamma && dy && dx && dgamma && dbeta, "ln_relu_bwd: NULL operand");
-  const int grid = min(cdiv(M, 4), 512);
+  const int grid = min(cdiv(M, 16), 1024);
   hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma, dy, dx, dgamma,
                      dbeta, M);
   DGPPO_LAUNCH_CHECK();
@@ -211,6 +243,7 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
       for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = hs_cur[(rt * 16 + li) * GRU_HL + kk * 4 + lq];
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 acc[RTW][3];
 #pragma unroll
       for (int rt = 0; rt < RTW; ++rt)
@@ -343,6 +376,7 @@ __global__ void __launch_bounds__(256) gru_bwd_kernel(GruArgs a) {
         for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
           for (int u = 0; u < 16; ++u) areg[rt][u] = s_g[(rt * 16 + li) * GRU_WL + (k0 + u) * 4 + lq];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 16; ++u)
 #pragma unroll

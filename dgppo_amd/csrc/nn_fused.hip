@@ -13,6 +13,16 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define FZ_RB 32           // rows per tile (2 row tiles of 16 per wave)
 #define FZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// sum over the 16 lanes of a DPP row (= the 16 columns a wave owns), result valid in every lane.  DPP moves stay inside
+// the VALU; __shfl_xor would go through the LDS crossbar (ds_bpermute) with a round trip per step.
+__device__ inline float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+
 struct MlpGiArgs {
   const float* X; int ldx; int M;
   const float *W1, *b1, *g1, *be1, *W2, *b2, *g2, *be2, *Wi, *bi;
@@ -25,7 +35,7 @@ struct MlpGiArgs {
 // stay resident while the workgroup walks 32-row tiles; the next tile's rows are requested while the current one
 // computes.  LayerNorm statistics: 16-lane shuffle reduction inside the wave, 4-way exchange through LDS.  Four LDS-only
 // barriers per tile.
-__global__ void __launch_bounds__(256) mlp_gi_fwd_kernel(MlpGiArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) mlp_gi_fwd_kernel(MlpGiArgs a) {
   extern __shared__ float sm[];
   float* s_x = sm;                              // [RB][HL]  input rows
   float* s_y1 = s_x + FZ_RB * FZ_HL;            // [RB][HL]  relu(LN(x W1 + b1))
@@ -73,19 +83,26 @@ __global__ void __launch_bounds__(256) mlp_gi_fwd_kernel(MlpGiArgs a) {
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float s = v[rt][r], q = v[rt][r] * v[rt][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 16); q += __shfl_xor(q, o, 16); }
+        const float s = row16_sum(v[rt][r]), q = row16_sum(v[rt][r] * v[rt][r]);
         if (li == 0) { float* d = s_red + (rt * 16 + lq * 4 + r) * 8 + 2 * w; d[0] = s; d[1] = q; }
       }
     FZ_LDS_BARRIER();
+    float4 pa[2][4], pb[2][4];            // all 16 reads in one LDS round trip
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rl = rt * 16 + lq * 4 + r;
-        const float4 p0 = *reinterpret_cast<const float4*>(s_red + rl * 8);
-        const float4 p1 = *reinterpret_cast<const float4*>(s_red + rl * 8 + 4);
+        pa[rt][r] = *reinterpret_cast<const float4*>(s_red + rl * 8);
+        pb[rt][r] = *reinterpret_cast<const float4*>(s_red + rl * 8 + 4);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = rt * 16 + lq * 4 + r;
+        const float4 p0 = pa[rt][r], p1 = pb[rt][r];
         const float mean = ((p0.x + p0.z) + (p1.x + p1.z)) * (1.0f / 64.0f);
         const float mean2 = ((p0.y + p0.w) + (p1.y + p1.w)) * (1.0f / 64.0f);
         const float var = fmaxf(mean2 - mean * mean, 0.0f);
@@ -117,6 +134,7 @@ __global__ void __launch_bounds__(256) mlp_gi_fwd_kernel(MlpGiArgs a) {
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_x[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    __builtin_amdgcn_sched_barrier(0);    // keep the 32 reads together: one LDS round trip, then MFMAs back to back
     acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
@@ -138,6 +156,7 @@ __global__ void __launch_bounds__(256) mlp_gi_fwd_kernel(MlpGiArgs a) {
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_y1[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    __builtin_amdgcn_sched_barrier(0);
     acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk)
@@ -157,6 +176,7 @@ __global__ void __launch_bounds__(256) mlp_gi_fwd_kernel(MlpGiArgs a) {
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_y2[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 ag[2][3];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)

@@ -73,3 +73,10 @@ if which in ("all", "attn"):
             timeit(f"attn_fwd G={G} F={F}", lambda: K.attn_fwd(cfg, F, 3, Kp, qt, Xa, Xo, ef, em, z, at, G))
             dq = torch.empty_like(qt); dXa = torch.empty_like(Xa); dXo = torch.empty_like(Xo)
             timeit(f"attn_bwd G={G} F={F}", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, dXa, dXo, G))
+if which in ("all", "fused"):
+    for M, train in ((32768, False), (131072, False), (131072, True)):
+        X = torch.randn(M, 64, device=dev)
+        P = [torch.randn(*s, device=dev) * 0.1 for s in ((64, 64), (64,), (64,), (64,), (64, 64), (64,), (64,), (64,), (64, 192), (192,))]
+        gi = torch.empty(M, 192, device=dev)
+        sv = tuple(torch.empty(M, w, device=dev) for w in (64, 64, 2, 64, 64, 2)) if train else None
+        timeit(f"mlp_gi_fwd M={M} train={train}", lambda: K.mlp_gi_fwd(X, *P, gi, sv))
