@@ -1,8 +1,5 @@
 // ABI plumbing shared by every entry point: version, thread-local error string, cfg validation.
 #include "common.h"
-#include <map>
-#include <mutex>
-#include <utility>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -16,46 +13,6 @@ void dgppo_set_error(const char* fmt, ...) {
 }
 
 extern "C" int32_t dgppo_abi_version(void) { return DGPPO_ABI_VERSION; }
-
-// ---- scratch buffers ------------------------------------------------------------------------------------------------
-namespace {
-constexpr size_t kWorkspaceBytes = size_t(64) << 20;
-std::mutex g_ws_mu;
-std::map<std::pair<int, hipStream_t>, float*> g_ws;
-}  // namespace
-
-float* dgppo_workspace(hipStream_t stream, size_t* bytes) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(g_ws_mu);
-  auto key = std::make_pair(dev, stream);
-  auto it = g_ws.find(key);
-  if (it == g_ws.end()) {
-    void* p = nullptr;
-    if (hipMalloc(&p, kWorkspaceBytes) != hipSuccess) {
-      (void)hipGetLastError();
-      p = nullptr;
-    }
-    it = g_ws.emplace(key, static_cast<float*>(p)).first;
-  }
-  if (bytes) *bytes = it->second ? kWorkspaceBytes : 0;
-  return it->second;
-}
-
-extern "C" int32_t dgppo_workspace_release(void) {
-  std::lock_guard<std::mutex> lock(g_ws_mu);
-  int cur = 0;
-  (void)hipGetDevice(&cur);
-  for (auto& kv : g_ws) {
-    if (!kv.second) continue;
-    (void)hipSetDevice(kv.first.first);
-    (void)hipDeviceSynchronize();
-    (void)hipFree(kv.second);
-  }
-  g_ws.clear();
-  (void)hipSetDevice(cur);
-  return 0;
-}
 extern "C" const char* dgppo_last_error(void) { return g_err; }
 
 int32_t dgppo_validate_cfg(const dgppo_env_cfg* c) {

@@ -9,10 +9,7 @@
 
 // ---- error plumbing (host) -------------------------------------------------------------------
 void dgppo_set_error(const char* fmt, ...);
-// Library-owned scratch memory for multi-stage reductions: one fixed-size buffer per (device, stream), allocated with
-// hipMalloc on first use and kept until dgppo_workspace_release().  Returns NULL (callers fall back to atomics) if the
-// allocation fails.  Kernels on one stream are ordered, so consecutive users of the same buffer cannot overlap.
-float* dgppo_workspace(hipStream_t stream, size_t* bytes);
+
 #define DGPPO_REQUIRE(cond, ...)            \
   do {                                      \
     if (!(cond)) {                          \

@@ -307,6 +307,7 @@ struct DenseBwdWArgs {
   int rows_per_block;
   float* part;        // scratch for per-workgroup partials [grid][part_stride], or NULL: atomicAdd straight into dW/db
   int part_stride;    // >= K*N + N
+  size_t ws_bytes;    // size of the caller's scratch buffer behind `part`
 };
 
 // A workgroup owns a contiguous chunk of rows and walks it in tiles of 32.  X[32,K] and dY[32,N] tiles live in LDS
@@ -316,9 +317,9 @@ struct DenseBwdWArgs {
 // column tiles over the tile's 8 four-row slabs (A[i=k][kk=m] = X[m][k], B[kk=m][j] = dY[m][j]).  K and N are padded to
 // KT*16 / NT*16 with zeros in LDS so the loop is branch-free; db's column sums are accumulated per lane from the
 // prefetch registers and reduced once at the end.  Write-out: every workgroup stores its K*N (+N) partial sums to a
-// scratch slab and dense_bwd_w_reduce_kernel folds the slabs into dW/db — with hundreds of workgroups finishing together,
-// atomicAdd on the same K*N addresses serialises (measured: 137 us vs 10 us for K=64, N=4).  Only launches of <= 4
-// workgroups (or a missing scratch buffer) use atomicAdd directly.
+// slab of the caller's workspace and dense_bwd_w_reduce_kernel folds the slabs into dW/db — with hundreds of workgroups
+// finishing together, atomicAdd on the same K*N addresses serialises (measured: 137 us vs 10 us for K=64, N=4).  Only
+// launches of <= 4 workgroups (or a NULL / too small workspace) use atomicAdd directly.
 #define BW_ROWS 32
 template <int NT, int KT>
 __global__ void __launch_bounds__(256) dense_bwd_w_kernel(DenseBwdWArgs a) {
@@ -547,8 +548,8 @@ static void launch_bwd_w_kt(DenseBwdWArgs a, hipStream_t s) {
   if (rpb < 2 * BW_ROWS) rpb = 2 * BW_ROWS;
   // partial slabs: stride rounded to 64 floats; shrink the grid if the scratch buffer cannot hold one slab per workgroup
   const int stride = ((a.K * a.N + a.N + 63) / 64) * 64;
-  size_t ws_bytes = 0;
-  float* ws = cdiv(a.M, rpb) > 4 ? dgppo_workspace(s, &ws_bytes) : nullptr;
+  const size_t ws_bytes = a.ws_bytes;
+  float* ws = cdiv(a.M, rpb) > 4 ? a.part : nullptr;
   if (ws) {
     const long max_slabs = (long)(ws_bytes / (sizeof(float) * stride));
     if (max_slabs < 8) ws = nullptr;
@@ -606,7 +607,18 @@ extern "C" int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, 
 }
 
 extern "C" int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
-                                     float* db, int32_t M, int32_t K, int32_t N, void* stream) {
-  DenseBwdWArgs a{X, ldx, dY, ldy, dW, ldw, db, M, K, N, 0, nullptr, 0};
+                                     float* db, int32_t M, int32_t K, int32_t N, float* workspace, int64_t workspace_bytes,
+                                     void* stream) {
+  DGPPO_REQUIRE(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0), "dense_bwd_w: bad workspace");
+  DGPPO_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dense_bwd_w: workspace must be 16-byte aligned");
+  DenseBwdWArgs a{X, ldx, dY, ldy, dW, ldw, db, M, K, N, 0, workspace, 0, (size_t)workspace_bytes};
   return dense_bwd_w_launch(a, (hipStream_t)stream);
+}
+
+// one slab of K*N + N floats (rounded to 64) per resident workgroup; 1024 workgroups cover every instantiation's
+// residency (<= 4 per CU x 256 CUs)
+extern "C" int64_t dgppo_dense_bwd_w_workspace_bytes(int32_t K, int32_t N) {
+  if (K < 1 || N < 1) return 0;
+  const int64_t stride = (((int64_t)K * N + N + 63) / 64) * 64;
+  return stride * 1024 * (int64_t)sizeof(float);
 }

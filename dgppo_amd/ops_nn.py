@@ -62,6 +62,22 @@ def mlp_gi_fwd(X, W1, b1, g1, be1, W2, b2, g2, be2, Wi, bi, gi, saves=None):
     N.check(rc, "dgppo_mlp_gi_fwd")
 
 
+_WS: dict = {}   # (device index, stream handle) -> scratch tensor for dense_bwd_w's partial sums (caller-owned, see the header)
+
+
+def _bwd_w_workspace(device, K: int, Ncol: int) -> torch.Tensor:
+    lib = N.lib()
+    lib.dgppo_dense_bwd_w_workspace_bytes.restype = C.c_int64
+    need = int(lib.dgppo_dense_bwd_w_workspace_bytes(C.c_int32(K), C.c_int32(Ncol)))
+    need = min(need, 64 << 20)                      # a smaller buffer only shrinks the grid
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
 def dense_bwd_w(X, dY, dW, db=None):
     """dW += X.T @ dY ; db += dY.sum(0)"""
     xp, ldx, M, K = _mat(X, "X")
@@ -71,7 +87,9 @@ def dense_bwd_w(X, dY, dW, db=None):
         raise ValueError(f"dense_bwd_w: shape mismatch X{tuple(X.shape)} dY{tuple(dY.shape)} dW{tuple(dW.shape)}")
     if db is not None:
         N.expect_shape(db, (Ncol,), "db")
-    rc = N.lib().dgppo_dense_bwd_w(xp, ldx, yp, ldy, wp, ldw, _p(db, "db"), M, K, Ncol, N.stream_ptr())
+    ws = _bwd_w_workspace(X.device, K, Ncol)
+    rc = N.lib().dgppo_dense_bwd_w(xp, ldx, yp, ldy, wp, ldw, _p(db, "db"), M, K, Ncol, _p(ws, "workspace"),
+                                   C.c_int64(ws.numel() * 4), N.stream_ptr())
     N.check(rc, "dgppo_dense_bwd_w")
 
 

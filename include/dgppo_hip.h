@@ -154,20 +154,13 @@ int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, int32_t ldw
 /* dW[K,N] += X^T dY ; db[N] += colsum(dY) (db may be NULL): the weight-gradient of a Dense
  * (jax.grad at dgppo/algo/informarl.py:377,440 ; dgppo/algo/dgppo.py:316).                          */
 int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
-                          float* db, int32_t M, int32_t K, int32_t N, void* stream);
-/* Fused row pipeline  x -> relu(LN(x W1 + b1)) -> relu(LN(. W2 + b2)) -> . Wi + bi  for 64-wide layers: the MLP trunk
- * (dgppo/nn/mlp.py:17-29, hid_sizes (64, 64)) followed by the GRUCell input projection (dgppo/nn/rnn.py:14-30) exactly as
- * PPOPolicy / ValueNet compose them (dgppo/algo/module/policy.py:191-212, value.py:58-80).  X [M,64] (row stride ldx),
- * W1/W2 [64,64], Wi [64,192] (r|z|n); gi [M,192].  p1,y1,p2,y2 [M,64] and st1,st2 [M,2] (mean, rstd) are the
- * activations the backward needs: pass all six or none (NULL).                                              */
-int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1, const float* b1, const float* g1,
-                         const float* be1, const float* W2, const float* b2, const float* g2, const float* be2,
-                         const float* Wi, const float* bi, float* p1, float* y1, float* st1, float* p2, float* y2,
-                         float* st2, float* gi, int32_t M, void* stream);
-/* dgppo_dense_bwd_w reduces per-workgroup partial sums through a library-owned scratch buffer: 64 MiB per
- * (device, stream), hipMalloc'ed on the first call that needs it (so not inside a stream capture) and kept until this
- * call frees them all.  No reference counterpart (XLA owns its scratch allocations).                        */
-int32_t dgppo_workspace_release(void);
+                          float* db, int32_t M, int32_t K, int32_t N, float* workspace, int64_t workspace_bytes,
+                          void* stream);
+/* Scratch for dgppo_dense_bwd_w's two-stage reduction (per-workgroup partial sums, then one reduce kernel): the caller
+ * owns it, like every other buffer (16-byte aligned device memory, reusable by consecutive calls on one stream).  The
+ * returned size lets every resident workgroup keep its own slab; a smaller buffer shrinks the grid, NULL / 0 falls back
+ * to atomicAdd into dW (correct, slower).  No reference counterpart (XLA owns its scratch allocations).      */
+int64_t dgppo_dense_bwd_w_workspace_bytes(int32_t K, int32_t N);
 
 /* Compact record -> per-graph dense features for the GNN: agent node rows Xa [G*n,Fp], other node rows
  * Xo [G*(Ns-n),Fp], per-(agent,slot) edge features [G*n,S,4] and masks [G*n,S] (1/0).  Graph g = e*n_time + t reads
