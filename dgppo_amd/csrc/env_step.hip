@@ -437,6 +437,8 @@ extern "C" int32_t dgppo_debug_stamps(unsigned long long* out) {
 #endif
 #define MISS_BITS 0x49742400u  // bits of 1e6f
 
+// workgroup barrier that waits for LDS traffic only (no vmcnt wait: outstanding global stores keep draining)
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <int SD, bool SPREAD, int NT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar_step_kernel(StepArgs a) {
   // requires n_rays == 32 (one half-wave per agent) — the host falls back to env_step_kernel otherwise
@@ -479,7 +481,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
   if (do_dyn) for (int i = tid; i < n * 2; i += nt) s_act[i] = clampf(a.action[(size_t)b * n * 2 + i], -1.0f, 1.0f);
   for (int i = tid; i < no * 16; i += nt) s_obst[i] = a.obst[(size_t)b * no * 16 + i];
   if (a.hits != nullptr) for (int i = tid; i < n * k * 2; i += nt) s_hpre[i] = a.hits[(size_t)b * n * k * 2 + i];
-  __syncthreads();
+  LDS_BARRIER();   // threads exchange data through LDS only; __syncthreads() would also wait for the global stores
   STAMP(1);
   // ---- P1a: per-segment constants, bounding circles, dynamics, features (disjoint lanes) ----
   if (do_sense) {
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
     state2feat<SD>(nx, s_fa + i * 4);
   }
   if (tid >= GO && tid < GO + n) state2feat<SD>(s_goal + (tid - GO) * SD, s_fg + (tid - GO) * 4);
-  __syncthreads();
+  LDS_BARRIER();   // threads exchange data through LDS only; __syncthreads() would also wait for the global stores
   STAMP(2);
   // ---- P1b: distances (one sqrt per thread) and start-inside flags ----
   {
@@ -550,7 +552,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
       }
     }
   }
-  __syncthreads();
+  LDS_BARRIER();   // threads exchange data through LDS only; __syncthreads() would also wait for the global stores
   STAMP(3);
   // ---- P1c: per-agent reductions (min is order independent), cost, reward terms ----
   if (do_dyn) {
@@ -626,7 +628,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
       }
     }
   }
-  __syncthreads();
+  LDS_BARRIER();   // threads exchange data through LDS only; __syncthreads() would also wait for the global stores
   STAMP(5);
   if (do_dyn && tid == 0) {
     float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
@@ -671,7 +673,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
   } else {
     for (int i = tid; i < n * k * 2; i += nt) s_hnext[i] = s_hpre[i];
   }
-  __syncthreads();
+  LDS_BARRIER();   // threads exchange data through LDS only; __syncthreads() would also wait for the global stores
   STAMP(7);
   // ---- P4: compact outputs ----
   if (a.next_agent != nullptr) for (int i = tid; i < n * SD; i += nt) a.next_agent[(size_t)b * n * SD + i] = s_next[i];
@@ -750,7 +752,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
     for (int node = tid; node < N; node += nt) nty[node] = (node < n) ? 0 : ((node < 2 * n) ? 1 : ((node < pad) ? 2 : -1));
     if (tid == 0) { a.g.n_node[b] = N; a.g.n_edge[b] = E; }
   }
-  __syncthreads();
+  LDS_BARRIER();   // threads exchange data through LDS only; __syncthreads() would also wait for the global stores
   {
     float* nodes = a.g.nodes + (size_t)b * N * ND;
     for (int idx = tid; idx < N * ND; idx += nt) nodes[idx] = s_outn[idx];
