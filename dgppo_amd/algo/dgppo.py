@@ -172,6 +172,13 @@ class DGPPO(Algorithm):
         ro = eng.rollout(self._seeds(keys), False)
         return self._wrap(ro, env)
 
+    def collect_stochastic(self, keys, env=None) -> Rollout:
+        """stochastic test rollouts (test.py:78-83 with --stochastic: algo.step inside test_rollout), batched"""
+        if env is not None and env is not self._env:
+            assert env.cfg.kind == self._env.cfg.kind and env.num_agents == self.n_agents
+        ro = self.engine.rollout(self._seeds(keys), True, noise_seed=int(self._rng.integers(1, 2 ** 62)))
+        return self._wrap(ro, env)
+
     def update(self, rollout: Rollout, step: int) -> dict:
         ro = self._last_rollouts.pop(id(rollout.actions), None)
         if ro is None:
