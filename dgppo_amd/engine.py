@@ -177,15 +177,23 @@ class Engine:
         slot["calls"] += 1
         if slot["graph"] is not None and slot["gen"] != self.arena.generation:
             slot["graph"] = None                               # a scratch buffer moved: the captured pointers are stale
-        if slot["graph"] is None and slot["calls"] >= 2:
+        if slot["graph"] is None and slot["calls"] >= 2 and not slot.get("failed", False):
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._rollout_steps(ro, eps, B, stochastic)
-            slot["graph"], slot["gen"] = graph, self.arena.generation
+            try:
+                # thread-local error mode: other threads (the RCCL watchdog of torch.distributed) keep issuing HIP calls
+                # while this thread captures; in the default global mode those would invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    self._rollout_steps(ro, eps, B, stochastic)
+                slot["graph"], slot["gen"] = graph, self.arena.generation
+            except Exception as ex:                             # keep training: eager launches are always correct
+                slot["failed"] = True
+                torch.cuda.synchronize()
+                print(f"[dgppo_amd] HIP-graph capture of the rollout loop failed ({type(ex).__name__}: {ex}); "
+                      f"continuing with eager launches", flush=True)
         if slot["graph"] is not None:
             slot["graph"].replay()
         else:
-            self._rollout_steps(ro, eps, B, stochastic)       # first call: eager (also sizes every scratch buffer)
+            self._rollout_steps(ro, eps, B, stochastic)       # first call (or capture unavailable): eager launches
         return ro
 
     # ------------------------------------------------------------------------------------------------------------------
