@@ -125,10 +125,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)       # ranks > devices only in rehearsals (several ranks sharing one GPU, gloo)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     from dgppo_amd import _native as N, engine as EN, init, dist as D
-    D.init(backend="nccl", device=device)
+    D.init(backend=os.environ.get("DGPPO_DIST_BACKEND", "nccl"), device=device)   # (gloo: rehearsal of N ranks on one GPU)
     allreduce = D.make_allreduce(world)          # RCCL all-reduce of each net's flat gradient buffer per minibatch step
     if allreduce is not None:                    # build the communicator outside any timed region
         allreduce(torch.zeros(1 << 16, device=device))
