@@ -81,7 +81,7 @@ class DGPPO(Algorithm):
                            Vh_gnn_layers=Vh_gnn_layers)
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce,
-                                use_graphs=True)
+                                use_graphs=True, multi_stream=True)
         self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
         self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
         self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3))

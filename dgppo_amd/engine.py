@@ -92,11 +92,14 @@ class OptState:
 class Engine:
     def __init__(self, cfg: N.EnvCfg, hyper: Hyper, device, T: int = 128,
                  allreduce: Optional[Callable[[torch.Tensor], None]] = None, prepass_graphs: int = 1 << 16,
-                 use_graphs: bool = False):
+                 use_graphs: bool = False, multi_stream: bool = False):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
         # HIP-graph replay of the launch-bound rollout loop (18 small kernels per env step).  Opt-in because the record
         # buffers then belong to the engine: a RolloutData stays valid only until the next rollout of the same kind.
         self.use_graphs = use_graphs and os.environ.get("DGPPO_HIPGRAPH", "1") != "0"
+        # run the Vl / Vh / policy updates of a minibatch on three HIP streams (they are independent)
+        self.multi_stream = multi_stream and os.environ.get("DGPPO_MULTI_STREAM", "1") != "0"
+        self._side_streams = None
         self._ro_cache: Dict[tuple, dict] = {}
         self.n_cost = 2
         self.policy = nets.Net("policy", cfg, hyper.actor_gnn_layers, 2, device)
@@ -253,6 +256,11 @@ class Engine:
                 w *= 2
         return w
 
+    def _net_streams(self):
+        if self._side_streams is None:
+            self._side_streams = [torch.cuda.Stream(self.device) for _ in range(3)]
+        return self._side_streams
+
     def _opt_step(self, name: str, lr: float):
         net, opt = self.nets[name], self.opt[name]
         if self.allreduce is not None:
@@ -294,40 +302,62 @@ class Engine:
         n_mb = B // Eb
         G = Eb * T
         R = G * n
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        side = self._net_streams() if (self.multi_stream and main is not None) else None
         for mb in range(n_mb):
             idx = idx_all[mb * Eb:(mb + 1) * Eb]
             idx32 = idx.to(torch.int32)
             self.stats[:3].zero_()
             self._mb = mb
+            # everything the three updates read is produced on the main stream first
             feats = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=idx32)
-            # ---- Vl (informarl.py:357-385): chunks of rnn_step with zero initial carry
-            act = self.Vl.forward(feats, n_seq=Eb * C, T=hp.rnn_step, h0=None, tag="tr")
-            dv = self.arena.get("mb.dv", G, 1)
-            Ql_mb = tg["Ql"].index_select(0, idx)
-            K.value_loss(act["v"], Ql_mb.view(G, 1), dv, self.stats[0])
-            self.Vl.zero_grads()
-            self.Vl.backward(act, dv)
-            self._opt_step("Vl", hp.lr_Vl)
-            # ---- Vh on the deterministic rollout with its stored carry (dgppo.py:296-321)
             feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=idx32)
-            h0 = det.rnn_states.index_select(0, idx).view(R, H)
-            act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0, tag="tr")
-            dvh = self.arena.get("mb.dvh", R, nh)
-            K.value_loss(act["v"], tg["Qh_det"].index_select(0, idx).view(R, nh), dvh, self.stats[1])
-            self.Vh.zero_grads()
-            self.Vh.backward(act, dvh)
-            self._opt_step("Vh", hp.lr_Vh)
-            # ---- policy (informarl.py:405-457)
-            act = self.policy.forward(feats, n_seq=Eb * C * n, T=hp.rnn_step, h0=None, tag="tr")
-            lp = self.arena.get("mb.lp", R)
-            ent = self.arena.get("mb.ent", R)
-            dms = self.arena.get("mb.dms", R, 4)
-            K.policy_head(act["ms"], self.eps_hat, ro.actions.index_select(0, idx).view(R, 2), None, lp, ent, n, 2,
-                          ro.log_pis.index_select(0, idx).view(R), tg["adv"].index_select(0, idx).view(R), dms,
-                          self.stats[2], hp.clip_eps, hp.coef_ent)
-            self.policy.zero_grads()
-            self.policy.backward(act, dms)
-            self._opt_step("policy", hp.lr_actor)
+            Ql_mb = tg["Ql"].index_select(0, idx)
+            h0_det = det.rnn_states.index_select(0, idx).view(R, H)
+            Qh_det_mb = tg["Qh_det"].index_select(0, idx).view(R, nh)
+            act_mb = ro.actions.index_select(0, idx).view(R, 2)
+            lp_old_mb = ro.log_pis.index_select(0, idx).view(R)
+            adv_mb = tg["adv"].index_select(0, idx).view(R)
+
+            def update_Vl():      # informarl.py:357-385: chunks of rnn_step with zero initial carry
+                act = self.Vl.forward(feats, n_seq=Eb * C, T=hp.rnn_step, h0=None, tag="tr")
+                dv = self.arena.get("mb.dv", G, 1)
+                K.value_loss(act["v"], Ql_mb.view(G, 1), dv, self.stats[0])
+                self.Vl.zero_grads()
+                self.Vl.backward(act, dv)
+                self._opt_step("Vl", hp.lr_Vl)
+
+            def update_Vh():      # dgppo.py:296-321: the deterministic rollout with its stored carry
+                act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det, tag="tr")
+                dvh = self.arena.get("mb.dvh", R, nh)
+                K.value_loss(act["v"], Qh_det_mb, dvh, self.stats[1])
+                self.Vh.zero_grads()
+                self.Vh.backward(act, dvh)
+                self._opt_step("Vh", hp.lr_Vh)
+
+            def update_policy():  # informarl.py:405-457
+                act = self.policy.forward(feats, n_seq=Eb * C * n, T=hp.rnn_step, h0=None, tag="tr")
+                lp = self.arena.get("mb.lp", R)
+                ent = self.arena.get("mb.ent", R)
+                dms = self.arena.get("mb.dms", R, 4)
+                K.policy_head(act["ms"], self.eps_hat, act_mb, None, lp, ent, n, 2, lp_old_mb, adv_mb, dms,
+                              self.stats[2], hp.clip_eps, hp.coef_ent)
+                self.policy.zero_grads()
+                self.policy.backward(act, dms)
+                self._opt_step("policy", hp.lr_actor)
+
+            if side is None:
+                update_Vl(); update_Vh(); update_policy()
+            else:
+                # the three networks share no state: one HIP stream each, joined before the next minibatch touches the
+                # shared inputs again (most of these kernels are latency-bound and leave CUs idle on their own)
+                ready = main.record_event()
+                for fn, st in ((update_policy, side[0]), (update_Vl, side[1]), (update_Vh, side[2])):
+                    with torch.cuda.stream(st):
+                        st.wait_event(ready)
+                        fn()
+                for st in side:
+                    main.wait_stream(st)
         self._last = dict(Ql_mb=Ql_mb, G=G, R=R, nh=nh, B=B)
         return self.info(ro)
 

@@ -150,3 +150,31 @@ def test_rollout_hip_graph_replay_is_bit_exact(cuda):
                     continue
                 assert torch.equal(x, y), f"call {call} stochastic={stochastic}: {name} differs"
     assert eng_g._ro_cache[(B, True)]["graph"] is not None and eng_g._ro_cache[(B, False)]["graph"] is not None
+
+
+def test_multi_stream_update_equals_single_stream(cuda):
+    """Engine(multi_stream=True) runs the Vl / Vh / policy updates of a minibatch on three HIP streams: after a full
+    update (several minibatches, i.e. several optimiser steps per network) the parameters must agree with the
+    single-stream engine to fp32 reduction-order noise."""
+    from dgppo_amd import engine as EN
+    B, T_, rs, bs = 8, 8, 4, 16
+    cfg, ocfg, hp, eng_a, trees = _setup("LidarSpread", 3, 2, B, T_, cuda, bs, rs)
+    eng_b = EN.Engine(cfg, hp, cuda, T=T_, multi_stream=True)
+    for k, net in eng_b.nets.items():
+        net.load_tree(trees[k])
+    eng_b.set_entropy_noise(77)
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    perm = np.random.default_rng(5).permutation(B)
+    infos = []
+    for eng in (eng_a, eng_b):
+        ro = eng.rollout(seeds, True, noise_seed=3)
+        det = eng.rollout(seeds + 1000, False)
+        infos.append(eng.update(ro, det, 10, perm))
+        torch.cuda.synchronize()
+    for name in ("Vl", "Vh", "policy"):
+        pa, pb = eng_a.nets[name].params, eng_b.nets[name].params
+        assert float(eng_a.opt[name].state[2]) == float(eng_b.opt[name].state[2]) == B // (bs // T_)
+        err = float((pa - pb).abs().max())
+        assert err <= 2e-5 * max(1.0, float(pa.abs().max())), f"{name}: parameters differ by {err:.3e}"
+    for k in ("Vl/loss", "Vh/loss_Vh", "policy/loss", "policy/entropy"):
+        assert abs(infos[0][k] - infos[1][k]) <= 1e-4 * max(1.0, abs(infos[0][k])), k
