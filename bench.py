@@ -147,27 +147,23 @@ def main():
     B = args.n_env
     rng = np.random.default_rng(1000 + rank)
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    phases = {"collect": 0.0, "det_rollout": 0.0, "update": 0.0}
+    phases = {"collect+det_rollout": 0.0, "update": 0.0}
 
     def iteration(it: int, timed: bool):
         seeds = torch.from_numpy(D.shard_seeds(rank, B, it)).to(device)
-        e = [ev() for _ in range(4)]
+        e = [ev() for _ in range(3)]
         e[0].record()
-        ro = eng.rollout(seeds, True, noise_seed=it * 2 + 1)                  # algo.collect
+        # algo.collect and the det_rollout_fn inside algo.update: same parameters, independent -> two HIP streams
+        ro, det = eng.rollout_pair(seeds, seeds ^ 0x5DEECE66D, noise_seed=it * 2 + 1)
         e[1].record()
         if it == 0:
-            torch.cuda.synchronize(); log("first collect done")
-        det = eng.rollout(seeds ^ 0x5DEECE66D, False)                         # det_rollout_fn inside algo.update
-        e[2].record()
-        if it == 0:
-            torch.cuda.synchronize(); log("first det rollout done")
+            torch.cuda.synchronize(); log("first rollouts done")
         info = eng.update(ro, det, it, rng.permutation(B))                    # rest of algo.update (+ info sync)
-        e[3].record()
+        e[2].record()
         if timed:
             torch.cuda.synchronize()
-            phases["collect"] += e[0].elapsed_time(e[1])
-            phases["det_rollout"] += e[1].elapsed_time(e[2])
-            phases["update"] += e[2].elapsed_time(e[3])
+            phases["collect+det_rollout"] += e[0].elapsed_time(e[1])
+            phases["update"] += e[1].elapsed_time(e[2])
         return info
 
     log(f"rank {rank}/{world}: engine ready, B={B} envs, starting {args.warmup} warm-up iteration(s)")
@@ -197,6 +193,15 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * T * args.steps / dt
     log(f"training timed: {ms_per_step:.1f} ms/iteration -> {value:.0f} env-steps/s; timing the raycast+graph kernel")
+    # the stochastic rollout alone (collect), timed after the training loop: env-steps/s of the rollout path by itself
+    seeds = torch.from_numpy(D.shard_seeds(rank, B, 10_000)).to(device)
+    eng.rollout(seeds, True, noise_seed=1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for r in range(3):
+        eng.rollout(seeds, True, noise_seed=2 + r)
+    torch.cuda.synchronize()
+    rollout_only = world * B * T * 3 / (time.perf_counter() - t1)
     rl = roofline_env_kernel(cfg, device, B) if cfg.is_lidar and cfg.n_obs > 0 else None
     log(f"roofline kernel: {rl}")
     out = {
@@ -209,7 +214,7 @@ def main():
                                f"of batch_size {args.batch_size}, rnn_step 16)",
                    "envs_per_gpu": B, "global_envs": world * B, "parallelism": f"dp{world}"},
         "phases_ms_per_step": {k: v / args.steps for k, v in phases.items()},
-        "rollout_only_env_steps_per_s": world * B * T / (phases["collect"] / args.steps / 1e3) if phases["collect"] else None,
+        "rollout_only_env_steps_per_s": rollout_only,
         "last_info": {k: info[k] for k in ("policy/loss", "Vl/loss", "Vh/loss_Vh", "eval/safe_data")},
     }
     if rl is not None:

@@ -162,7 +162,12 @@ class DGPPO(Algorithm):
     def collect(self, params, keys) -> Rollout:
         """algo.collect(params, keys): one stochastic rollout per key (informarl.py:254-256)."""
         self._maybe_load(params)
-        ro = self.engine.rollout(self._seeds(keys), True, noise_seed=int(self._rng.integers(1, 2 ** 62)))
+        seeds = self._seeds(keys)
+        # the deterministic rollout that update() needs for the constraint-value targets (dgppo.py:139-141) uses the same
+        # parameters as this collect: it is launched alongside on a second stream and handed to update()
+        det_seeds = self._seeds(self._rng.integers(1, 2 ** 62, size=int(seeds.shape[0])))
+        ro, det = self.engine.rollout_pair(seeds, det_seeds, noise_seed=int(self._rng.integers(1, 2 ** 62)))
+        self._pending_det = (ro, det)
         return self._wrap(ro)
 
     def collect_deterministic(self, keys, env=None) -> Rollout:
@@ -184,8 +189,13 @@ class DGPPO(Algorithm):
         if ro is None:
             raise ValueError("update() needs a Rollout produced by this algo's collect()")
         self._last_rollouts.clear()
-        # deterministic rollout for the constraint-value targets (dgppo.py:139-141)
-        det = self.engine.rollout(self._seeds(self._rng.integers(1, 2 ** 62, size=ro.B)), False)
+        # deterministic rollout for the constraint-value targets (dgppo.py:139-141): produced next to collect()
+        pend = getattr(self, "_pending_det", None)
+        self._pending_det = None
+        if pend is not None and pend[0] is ro:
+            det = pend[1]
+        else:
+            det = self.engine.rollout(self._seeds(self._rng.integers(1, 2 ** 62, size=ro.B)), False)
         perm = np.arange(ro.B)
         np.random.shuffle(perm)                              # host np.random like the reference (dgppo.py:155-156)
         return self.engine.update(ro, det, int(step), perm)

@@ -138,10 +138,11 @@ class Engine:
     def _rollout_steps(self, ro: RolloutData, eps, B: int, stochastic: bool):
         """the T env steps of a rollout: policy forward (GNN + GRU + head) and env.step, all on the current stream."""
         cfg, T, n = self.cfg, self.T, self.cfg.n_agents
+        tag = "ro" if stochastic else "rod"    # separate scratch per kind: the two rollouts may run on different streams
         for t in range(T):
             hits_t = ro.hits_tm[t] if ro.has_hits else None
-            feats = self._feats_at("ro", ro.agent_tm[t], hits_t, ro.goal, ro.obst, B)
-            act = self.policy.forward(feats, n_seq=B * n, T=1, h0=ro.rnn_tm[t].view(B * n, nets.HID), tag="ro",
+            feats = self._feats_at(tag, ro.agent_tm[t], hits_t, ro.goal, ro.obst, B)
+            act = self.policy.forward(feats, n_seq=B * n, T=1, h0=ro.rnn_tm[t].view(B * n, nets.HID), tag=tag,
                                       hs_out=ro.rnn_tm[t + 1].view(B * n, nets.HID), train=False)
             a_t = ro.action_tm[t].view(B * n, 2)
             if stochastic:
@@ -198,6 +199,22 @@ class Engine:
         else:
             self._rollout_steps(ro, eps, B, stochastic)       # first call (or capture unavailable): eager launches
         return ro
+
+    def rollout_pair(self, seeds: torch.Tensor, det_seeds: torch.Tensor, noise_seed: int = 0):
+        """the stochastic training rollout and the deterministic rollout of the same parameters (informarl.py:254-256 and
+        dgppo.py:139-141).  They are independent, so with multi_stream they run on two HIP streams side by side."""
+        if not (self.multi_stream and self.device.type == "cuda"):
+            return self.rollout(seeds, True, noise_seed), self.rollout(det_seeds, False)
+        main = torch.cuda.current_stream(self.device)
+        s0, s1 = self._net_streams()[:2]
+        out = [None, None]
+        for k, (st, sd, stoch) in enumerate(((s0, seeds, True), (s1, det_seeds, False))):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out[k] = self.rollout(sd, stoch, noise_seed if stoch else 0)
+        main.wait_stream(s0)
+        main.wait_stream(s1)
+        return out[0], out[1]
 
     # ------------------------------------------------------------------------------------------------------------------
     # value pre-passes (dgppo.py:204-229, 262-264)
