@@ -1517,10 +1517,10 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   bool launched = false;
   if (mfma_ok && (Kp & 3) == 0 && t.n * H * H < 65536 && !getenv("DGPPO_ATTN_BLOCK")) {
     const int grid = (G + 3) / 4;
+    // instantiated for the widths the reference's defaults produce (node features padded to 8, msg_dim 32); other
+    // multiples of 4 take the workgroup-per-graph kernels below
     if (F == 8) launched = launch_attn_wave<8>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
-    else if (F == 16) launched = launch_attn_wave<16>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
-    else if (F == 64) launched = launch_attn_wave<64>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
   }
   if (launched) {
   } else if (pers_ok) {
@@ -1566,9 +1566,7 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
       !getenv("DGPPO_ATTN_BLOCK")) {
     const int grid = (G + 3) / 4, NP = (d.nH + 7) / 8, SJ = (t.S + 7) / 8;
     if (F == 8) launched = launch_attn_wave<8>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
-    else if (F == 16) launched = launch_attn_wave<16>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
-    else if (F == 64) launched = launch_attn_wave<64>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
   }
   if (launched) {
   }

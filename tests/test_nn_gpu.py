@@ -414,3 +414,54 @@ def test_tree_roundtrip_and_param_counts(cuda):
         assert sum(v.numel() for v in leaves_a.values()) == count
         for k in leaves_a:
             np.testing.assert_array_equal(leaves_a[k].numpy(), leaves_b[k])
+
+
+@pytest.mark.parametrize("F,Kp", [(8, 48), (32, 144), (16, 80)])
+def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
+    """dgppo_attn_fwd/bwd dispatch between the one-wave-per-graph kernels (default for F in {8, 32}), the workgroup-per-
+    graph MFMA kernels (persistent and plain) and the VALU kernels.  The default path is pinned to the oracle by the
+    network tests below; this pins every fallback to the default path on the same random inputs (masked slots, NaN edge
+    features behind the mask).  F = 16 has no wave instantiation: there the MFMA and VALU families are compared."""
+    from dgppo_amd import _native as N, ops_nn as K_
+    cfg = N.make_env_cfg(0, 8, 3)
+    n, S, H = 8, cfg.fan_in, 3
+    n_other = cfg.num_nodes - 1 - n
+    G = 37
+    g = torch.Generator().manual_seed(F)
+    R = G * n
+    qt = torch.randn(R, H * F, generator=g).to(cuda)
+    Xa = torch.randn(R, F, generator=g).to(cuda)
+    Xo = torch.randn(G * n_other, F, generator=g).to(cuda)
+    em = (torch.rand(R, S, generator=g) > 0.35).float()
+    em[:, :n] = 1.0
+    ef = torch.randn(R, S, 4, generator=g)
+    ef[em == 0] = float("nan")                 # masked slots must never be multiplied
+    em, ef = em.to(cuda), ef.to(cuda)
+    dz = torch.randn(R, Kp, generator=g).to(cuda)
+
+    def run():
+        z = torch.full((R, Kp), float("nan"), device=cuda)
+        at = torch.full((R, S, H), float("nan"), device=cuda)
+        K_.attn_fwd(cfg, F, H, Kp, qt, Xa, Xo, ef, em, z, at, G)
+        dq = torch.full((R, H * F), float("nan"), device=cuda)
+        dXa = torch.full((R, F), float("nan"), device=cuda)
+        dXo = torch.full((G * n_other, F), float("nan"), device=cuda)
+        K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo, ef, dq, dXa, dXo, G)
+        torch.cuda.synchronize()
+        return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo)
+
+    families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "block_v1": {"DGPPO_ATTN_BLOCK": "1", "DGPPO_ATTN_V1": "1"},
+                "valu": {"DGPPO_ATTN_VALU": "1"}}
+    outs = {}
+    for name, env in families.items():
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[name] = run()
+        for k in env:
+            monkeypatch.delenv(k)
+    ref = outs["default"]
+    for k, v in ref.items():
+        assert torch.isfinite(v).all(), f"default path left non-finite values in {k}"
+    for name in ("block", "block_v1", "valu"):
+        for k in ref:
+            _close(outs[name][k], ref[k], 2e-5, f"{name}.{k}")
