@@ -158,7 +158,7 @@ class Engine:
         n = cfg.n_agents
         slot = None
         if self.use_graphs:
-            # persistent record buffers per (B, kind): eager on the first call, captured on the second, replayed after
+            # persistent record buffers per (B, kind): eager + capture on the first call, replayed afterwards
             slot = self._ro_cache.setdefault((B, stochastic), {"ro": None, "graph": None, "gen": -1, "calls": 0})
             if slot["ro"] is None:
                 slot["ro"] = RolloutData(cfg, B, T, self.device, stochastic)
@@ -179,26 +179,36 @@ class Engine:
             self._rollout_steps(ro, eps, B, stochastic)
             return ro
         slot["calls"] += 1
-        if slot["graph"] is not None and slot["gen"] != self.arena.generation:
+        if slot["graph"] is not None and slot["gen"] != self._arena_generation():
             slot["graph"] = None                               # a scratch buffer moved: the captured pointers are stale
-        if slot["graph"] is None and slot["calls"] >= 2 and not slot.get("failed", False):
+        if slot["graph"] is not None:
+            slot["graph"].replay()
+            return ro
+        # first call (or stale graph): eager launches — they also size every scratch buffer — then capture the same loop
+        # right away, so that the second call already replays (one warm-up iteration is enough for steady state)
+        self._rollout_steps(ro, eps, B, stochastic)
+        if not slot.get("failed", False):
             graph = torch.cuda.CUDAGraph()
             try:
                 # thread-local error mode: other threads (the RCCL watchdog of torch.distributed) keep issuing HIP calls
-                # while this thread captures; in the default global mode those would invalidate the capture
+                # while this thread captures; in the default global mode those would invalidate the capture.
+                # Capturing records the launches without executing them: the results of the eager pass above stand.
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._rollout_steps(ro, eps, B, stochastic)
-                slot["graph"], slot["gen"] = graph, self.arena.generation
+                slot["graph"], slot["gen"] = graph, self._arena_generation()
+                # the first launch of a ~2300-node graph uploads it to the device (~100 ms): pay that here, in the same
+                # warm-up call (same inputs, so it rewrites the record with identical values)
+                graph.replay()
             except Exception as ex:                             # keep training: eager launches are always correct
                 slot["failed"] = True
                 torch.cuda.synchronize()
                 print(f"[dgppo_amd] HIP-graph capture of the rollout loop failed ({type(ex).__name__}: {ex}); "
                       f"continuing with eager launches", flush=True)
-        if slot["graph"] is not None:
-            slot["graph"].replay()
-        else:
-            self._rollout_steps(ro, eps, B, stochastic)       # first call (or capture unavailable): eager launches
         return ro
+
+    def _arena_generation(self) -> int:
+        """scratch buffers the rollout loop touches live in the engine's arena (features) and the policy's (activations)"""
+        return self.arena.generation + self.policy.arena.generation
 
     def rollout_pair(self, seeds: torch.Tensor, det_seeds: torch.Tensor, noise_seed: int = 0):
         """the stochastic training rollout and the deterministic rollout of the same parameters (informarl.py:254-256 and

@@ -78,15 +78,16 @@ class Arena:
     def __init__(self, device):
         self.device = device
         self.bufs: Dict[str, torch.Tensor] = {}
-        self.generation = 0          # bumped whenever a buffer is (re)allocated: captured HIP graphs check it before replay
+        self.generation = 0          # bumped whenever a buffer is re-allocated (moves): captured HIP graphs check it before replay
 
     def get(self, name: str, *shape, dtype=torch.float32, zero=False) -> torch.Tensor:
         n = int(np.prod(shape))
         b = self.bufs.get(name)
         if b is None or b.numel() < n or b.dtype != dtype:
+            if b is not None:
+                self.generation += 1     # an existing buffer moves: pointers baked into captured graphs are stale
             b = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self.bufs[name] = b
-            self.generation += 1
         v = b[:n].view(*shape)
         if zero:
             v.zero_()
