@@ -1,0 +1,30 @@
+"""Developer tool: wall time of the pieces of Engine.update (value pre-passes + GAE + advantage vs the minibatch loop)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dgppo_amd import _native as N, init
+from dgppo_amd.engine import Engine, Hyper
+
+dev = torch.device("cuda:0")
+cfg = N.make_env_cfg(0, 8, 3)
+B = 4096
+hp = Hyper(batch_size=16384, train_steps=1000)
+eng = Engine(cfg, hp, dev, use_graphs=True, multi_stream=os.environ.get("MS", "1") == "1")
+eng.policy.load_tree(init.init_policy(0, cfg.node_dim, 2, hp.actor_gnn_layers))
+eng.Vl.load_tree(init.init_value(0, cfg.node_dim, 1, hp.Vl_gnn_layers, 2))
+eng.Vh.load_tree(init.init_value(0, cfg.node_dim, 2, hp.Vh_gnn_layers, 3))
+eng.set_entropy_noise(1)
+seeds = torch.arange(1, B + 1, device=dev, dtype=torch.int64)
+rng = np.random.default_rng(0)
+for it in range(4):
+    ro, det = eng.rollout_pair(seeds + it, seeds + 100000 + it, noise_seed=it + 1)
+    ro.finalize(); det.finalize()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tg = eng.targets(ro, det, it)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    orig = eng.targets
+    eng.targets = lambda *a, **k: tg            # reuse: time the minibatch loop alone
+    eng.update(ro, det, it, rng.permutation(B))
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    eng.targets = orig
+    print(f"iter {it}: targets (pre-passes + 2 GAE + advantage) {1e3 * (t1 - t0):.1f} ms, 32 minibatches {1e3 * (t2 - t1):.1f} ms")
