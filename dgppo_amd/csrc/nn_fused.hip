@@ -226,3 +226,205 @@ extern "C" int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One GRU step (T = 1) + the output Dense layer(s) on the same rows: the tail of PPOPolicy.get_action / ValueNet.get_value
+// in a rollout step (dgppo/nn/rnn.py:14-30 -> dgppo/algo/module/policy.py:62-74 [PolicyNet head Dense(64) -> TanhNormal
+// Dense(4)], value.py:41,76 [Dense(n_out)]).
+//   h' = GRU(gi, h0)      gi = x Wi + bi precomputed (mlp_gi_fwd_kernel),  r|z|n gate order, flax GRUCell
+//   TWO = true :  u = h' W1 + b1  [64]   out = u W2 + b2   [n_out <= 16]       (policy)
+//   TWO = false:  out = h' W1 + b1  [n_out <= 16]                               (value nets)
+// Persistent 32-row tiles; Wh (48) + W1 (16) + W2 (16) k-step fragments stay in registers; h0 / h' / u tiles in LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+struct GruHeadArgs {
+  const float *gi, *Wh, *bhn, *h0;        // gi [M,192], Wh [64,192], bhn [64], h0 [M,64] or NULL (zeros)
+  const float *W1, *b1, *W2, *b2;         // TWO: W1 [64,64], W2 [64,n_out];  else W1 [64,n_out], W2 unused
+  float *hs, *hprev, *gates, *u, *out;    // hs [M,64]; hprev [M,64] / gates [M,256] / u [M,64] saved for training or NULL
+  int M, n_out;
+};
+__device__ inline float fz_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <bool TWO>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) gru1_head_fwd_kernel(GruHeadArgs a) {
+  extern __shared__ float sm[];
+  float* s_h = sm;                          // [RB][HL] h0 rows
+  float* s_n = s_h + FZ_RB * FZ_HL;         // [RB][HL] h' rows
+  float* s_u = s_n + FZ_RB * FZ_HL;         // [RB][HL] u rows (TWO)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int c = w * 16 + li;
+  float wh[16][3], w1[16], w2[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = kk * 4 + lq;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wh[kk][t] = a.Wh[k * 192 + t * 64 + c];
+    if (TWO) {
+      w1[kk] = a.W1[k * FZ_H + c];
+      w2[kk] = (li < a.n_out) ? a.W2[k * a.n_out + li] : 0.0f;      // single column tile: identical in every wave
+    } else {
+      w1[kk] = (li < a.n_out) ? a.W1[k * a.n_out + li] : 0.0f;
+      w2[kk] = 0.0f;
+    }
+  }
+  const float bn = a.bhn[c];
+  const float b1 = TWO ? a.b1[c] : ((li < a.n_out) ? a.b1[li] : 0.0f);
+  const float b2 = (TWO && li < a.n_out) ? a.b2[li] : 0.0f;
+  const int n_tiles = (a.M + FZ_RB - 1) / FZ_RB;
+  float hpf[2][4];
+  auto fetch_h0 = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = u * 256 + tid, r = idx >> 4, q = idx & 15;
+      int row = tile * FZ_RB + r;
+      row = row < a.M ? row : a.M - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.h0 != nullptr) v = reinterpret_cast<const float4*>(a.h0 + (size_t)row * FZ_H)[q];
+      hpf[u][0] = v.x; hpf[u][1] = v.y; hpf[u][2] = v.z; hpf[u][3] = v.w;
+    }
+  };
+  auto commit_h0 = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = u * 256 + tid, r = idx >> 4, q = idx & 15;
+      float* d = s_h + r * FZ_HL + 4 * q;
+      d[0] = hpf[u][0]; d[1] = hpf[u][1]; d[2] = hpf[u][2]; d[3] = hpf[u][3];
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < n_tiles) { fetch_h0(tile); commit_h0(); }
+  __syncthreads();
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int row0 = tile * FZ_RB;
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < n_tiles;
+    // gate inputs of this tile and the next tile's h0 rows: requested before the MFMAs
+    float g[2][4][3];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + rt * 16 + lq * 4 + r;
+        row = row < a.M ? row : a.M - 1;
+        const float* gp = a.gi + (size_t)row * 192 + c;
+        g[rt][r][0] = gp[0]; g[rt][r][1] = gp[64]; g[rt][r][2] = gp[128];
+      }
+    if (more) fetch_h0(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    float areg[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_h[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], wh[kk][t], acc[rt][t], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = rt * 16 + lq * 4 + r, row = row0 + rl;
+        const float hp = s_h[rl * FZ_HL + c];
+        const float rg = fz_sigmoid(g[rt][r][0] + acc[rt][0][r]);
+        const float zg = fz_sigmoid(g[rt][r][1] + acc[rt][1][r]);
+        const float hn = acc[rt][2][r] + bn;
+        const float ng = tanhf(g[rt][r][2] + rg * hn);
+        const float hnew = (1.0f - zg) * ng + zg * hp;
+        s_n[rl * FZ_HL + c] = hnew;
+        if (row < a.M) {
+          a.hs[(size_t)row * FZ_H + c] = hnew;
+          if (a.hprev != nullptr) a.hprev[(size_t)row * FZ_H + c] = hp;
+          if (a.gates != nullptr) {
+            float* gs = a.gates + (size_t)row * 256;
+            gs[c] = rg; gs[64 + c] = zg; gs[128 + c] = ng; gs[192 + c] = hn;
+          }
+        }
+      }
+    FZ_LDS_BARRIER();                     // h' complete; every read of s_h is done
+    if (more) commit_h0();
+    // ---- first Dense on h' ----
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_n[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+    __builtin_amdgcn_sched_barrier(0);
+    if (TWO) {
+      f32x4 au[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) au[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], w1[kk], au[rt], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = rt * 16 + lq * 4 + r, row = row0 + rl;
+          const float uv = au[rt][r] + b1;
+          s_u[rl * FZ_HL + c] = uv;
+          if (a.u != nullptr && row < a.M) a.u[(size_t)row * FZ_H + c] = uv;
+        }
+      FZ_LDS_BARRIER();
+      // ---- second Dense: one column tile, row tile w (waves 0 and 1) ----
+      if (w < 2) {
+        float ar[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) ar[kk] = s_u[(w * 16 + li) * FZ_HL + kk * 4 + lq];
+        f32x4 ao = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) ao = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[kk], w2[kk], ao, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + w * 16 + lq * 4 + r;
+          if (row < a.M && li < a.n_out) a.out[(size_t)row * a.n_out + li] = ao[r] + b2;
+        }
+      }
+    } else if (w < 2) {
+      f32x4 ao = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) ao = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[w][kk], w1[kk], ao, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + w * 16 + lq * 4 + r;
+        if (row < a.M && li < a.n_out) a.out[(size_t)row * a.n_out + li] = ao[r] + b1;
+      }
+    }
+    FZ_LDS_BARRIER();                     // next tile's h0 committed; s_n / s_u free again
+  }
+}
+
+extern "C" int32_t dgppo_gru1_head_fwd(const float* gi, const float* Wh, const float* bhn, const float* h0, const float* W1,
+                                       const float* b1, const float* W2, const float* b2, float* hs, float* hprev,
+                                       float* gates, float* u, float* out, int32_t M, int32_t n_out, void* stream) {
+  DGPPO_REQUIRE(M >= 0 && n_out >= 1 && n_out <= 16, "gru1_head_fwd: bad shape M=%d n_out=%d", M, n_out);
+  DGPPO_REQUIRE(gi && Wh && bhn && W1 && b1 && hs && out, "gru1_head_fwd: NULL operand");
+  const bool two = W2 != nullptr;
+  DGPPO_REQUIRE(!two || b2, "gru1_head_fwd: W2 without b2");
+  DGPPO_REQUIRE(two || !u, "gru1_head_fwd: u is only produced by the two-layer head");
+  if (M == 0) return 0;
+  GruHeadArgs a{gi, Wh, bhn, h0, W1, b1, W2, b2, hs, hprev, gates, u, out, M, n_out};
+  const size_t smem = sizeof(float) * 3 * FZ_RB * FZ_HL;
+  const void* fn = two ? reinterpret_cast<const void*>(&gru1_head_fwd_kernel<true>)
+                       : reinterpret_cast<const void*>(&gru1_head_fwd_kernel<false>);
+  static thread_local int cap[2] = {0, 0};
+  if (cap[two] == 0) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cap[two] = per_cu * cus;
+  }
+  const int tiles = (M + FZ_RB - 1) / FZ_RB;
+  const int grid = tiles < cap[two] ? tiles : cap[two];
+  if (two) hipLaunchKernelGGL(gru1_head_fwd_kernel<true>, dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gru1_head_fwd_kernel<false>, dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}

@@ -62,6 +62,27 @@ def mlp_gi_fwd(X, W1, b1, g1, be1, W2, b2, g2, be2, Wi, bi, gi, saves=None):
     N.check(rc, "dgppo_mlp_gi_fwd")
 
 
+def gru1_head_fwd(gi, Wh, bhn, h0, W1, b1, W2, b2, hs, hprev, gates, u, out):
+    """one GRU step (T = 1) + head Dense(s): out = (h' W1 + b1) [W2 + b2]; see dgppo_gru1_head_fwd in the header."""
+    M = gi.shape[0]
+    n_out = out.shape[1]
+    N.expect_shape(gi, (M, 192), "gi"); N.expect_shape(Wh, (64, 192), "Wh"); N.expect_shape(bhn, (64,), "bhn")
+    N.expect_shape(hs, (M, 64), "hs"); N.expect_shape(out, (M, n_out), "out")
+    if h0 is not None:
+        N.expect_shape(h0, (M, 64), "h0")
+    if W2 is not None:
+        N.expect_shape(W1, (64, 64), "W1"); N.expect_shape(b1, (64,), "b1")
+        N.expect_shape(W2, (64, n_out), "W2"); N.expect_shape(b2, (n_out,), "b2")
+    else:
+        N.expect_shape(W1, (64, n_out), "W1"); N.expect_shape(b1, (n_out,), "b1")
+    for t, shp, nm in ((hprev, (M, 64), "hprev"), (gates, (M, 256), "gates"), (u, (M, 64), "u")):
+        if t is not None:
+            N.expect_shape(t, shp, nm)
+    rc = N.lib().dgppo_gru1_head_fwd(_p(gi), _p(Wh), _p(bhn), _p(h0), _p(W1), _p(b1), _p(W2), _p(b2), _p(hs), _p(hprev),
+                                     _p(gates), _p(u), _p(out), M, n_out, N.stream_ptr())
+    N.check(rc, "dgppo_gru1_head_fwd")
+
+
 _WS: dict = {}   # (device index, stream handle) -> scratch tensor for dense_bwd_w's partial sums (caller-owned, see the header)
 
 

@@ -156,6 +156,14 @@ int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, int32_t ldw
 int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
                           float* db, int32_t M, int32_t K, int32_t N, float* workspace, int64_t workspace_bytes,
                           void* stream);
+/* One GRU step (T = 1) fused with the output Dense layer(s) on the same rows — the tail of a rollout step:
+ * h' = GRUCell(gi, h0) (dgppo/nn/rnn.py:14-30, gi = x W_i + b_i from dgppo_mlp_gi_fwd), then either the policy head
+ * u = h' W1 + b1 [64], out = u W2 + b2 (PolicyNet.head Dense -> TanhNormal Dense, dgppo/algo/module/policy.py:62-74; pass
+ * W2/b2) or a value head out = h' W1 + b1 (dgppo/algo/module/value.py:41,76; W2 = b2 = NULL).  n_out <= 16.  hprev [M,64],
+ * gates [M,256] (r|z|n|hn_lin) and u [M,64] are the activations the backward needs (each may be NULL).       */
+int32_t dgppo_gru1_head_fwd(const float* gi, const float* Wh, const float* bhn, const float* h0, const float* W1,
+                            const float* b1, const float* W2, const float* b2, float* hs, float* hprev, float* gates,
+                            float* u, float* out, int32_t M, int32_t n_out, void* stream);
 /* Scratch for dgppo_dense_bwd_w's two-stage reduction (per-workgroup partial sums, then one reduce kernel): the caller
  * owns it, like every other buffer (16-byte aligned device memory, reusable by consecutive calls on one stream).  The
  * returned size lets every resident workgroup keep its own slab; a smaller buffer shrinks the grid, NULL / 0 falls back

@@ -101,6 +101,51 @@ def test_mlp_gi_fused(cuda, M, save, strided):
             _close(got, want, 2e-5, nm)
 
 
+@pytest.mark.parametrize("M,two,use_h0,save", [(1, True, True, True), (45, False, False, False), (1000, True, False, True),
+                                               (33000, False, True, True), (33000, True, True, False)])
+def test_gru1_head_fused(cuda, M, two, use_h0, save):
+    """fused one-step GRU + head Dense(s) against the plain torch fp32 composition (flax GRUCell gate order r|z|n,
+    rnn.py:14-30; policy.py:62-74 / value.py:41,76), ragged M, zero or given initial carry, with and without saves."""
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M + 7)
+    n_out = 4 if two else 2
+    gi = torch.randn(M, 192, generator=g)
+    h0 = torch.randn(M, 64, generator=g) if use_h0 else None
+    Wh = torch.randn(64, 192, generator=g) * 0.2
+    bhn = torch.randn(64, generator=g) * 0.1
+    if two:
+        W1, b1 = torch.randn(64, 64, generator=g) * 0.2, torch.randn(64, generator=g) * 0.1
+        W2, b2 = torch.randn(64, n_out, generator=g) * 0.2, torch.randn(n_out, generator=g) * 0.1
+    else:
+        W1, b1, W2, b2 = torch.randn(64, n_out, generator=g) * 0.2, torch.randn(n_out, generator=g) * 0.1, None, None
+    h = h0 if use_h0 else torch.zeros(M, 64)
+    gh = h @ Wh
+    r = torch.sigmoid(gi[:, :64] + gh[:, :64])
+    z = torch.sigmoid(gi[:, 64:128] + gh[:, 64:128])
+    hn = gh[:, 128:] + bhn
+    nn_ = torch.tanh(gi[:, 128:] + r * hn)
+    hnew = (1 - z) * nn_ + z * h
+    if two:
+        u_want = hnew @ W1 + b1
+        out_want = u_want @ W2 + b2
+    else:
+        u_want, out_want = None, hnew @ W1 + b1
+    d = lambda t: None if t is None else t.to(cuda)
+    hs = torch.full((M, 64), float("nan"), device=cuda)
+    out = torch.full((M, n_out), float("nan"), device=cuda)
+    hprev = torch.full((M, 64), float("nan"), device=cuda) if save else None
+    gates = torch.full((M, 256), float("nan"), device=cuda) if save else None
+    u = torch.full((M, 64), float("nan"), device=cuda) if (save and two) else None
+    K_.gru1_head_fwd(d(gi), d(Wh), d(bhn), d(h0), d(W1), d(b1), d(W2), d(b2), hs, hprev, gates, u, out)
+    _close(hs, hnew, 1e-5, "hs")
+    _close(out, out_want, 2e-5, "out")
+    if save:
+        _close(hprev, h, 1e-6, "hprev")
+        _close(gates, torch.cat([r, z, nn_, hn], 1), 1e-5, "gates")
+        if two:
+            _close(u, u_want, 2e-5, "u")
+
+
 def test_ln_relu(cuda):
     from dgppo_amd import ops_nn as K_
     g = torch.Generator().manual_seed(0)

@@ -80,3 +80,23 @@ if which in ("all", "fused"):
         gi = torch.empty(M, 192, device=dev)
         sv = tuple(torch.empty(M, w, device=dev) for w in (64, 64, 2, 64, 64, 2)) if train else None
         timeit(f"mlp_gi_fwd M={M} train={train}", lambda: K.mlp_gi_fwd(X, *P, gi, sv))
+if which in ("all", "tail"):
+    for M, two, train in ((32768, True, False), (131072, False, True), (524288, False, False)):
+        gi = torch.randn(M, 192, device=dev); h0 = torch.randn(M, 64, device=dev)
+        Wh = torch.randn(64, 192, device=dev) * 0.1; bhn = torch.zeros(64, device=dev)
+        n_out = 4 if two else 2
+        W1 = torch.randn(64, 64 if two else n_out, device=dev) * 0.1; b1 = torch.zeros(64 if two else n_out, device=dev)
+        W2 = torch.randn(64, n_out, device=dev) * 0.1 if two else None; b2 = torch.zeros(n_out, device=dev) if two else None
+        hs = torch.empty(M, 64, device=dev); out = torch.empty(M, n_out, device=dev)
+        hp = torch.empty(M, 64, device=dev) if train else None; gt = torch.empty(M, 256, device=dev) if train else None
+        u = torch.empty(M, 64, device=dev)
+        timeit(f"gru1_head_fwd fused M={M} two={two} train={train}",
+               lambda: K.gru1_head_fwd(gi, Wh, bhn, h0, W1, b1, W2, b2, hs, hp, gt, u if (two and train) else None, out))
+
+        def unfused():
+            K.gru_fwd(gi, Wh, bhn, h0, hs, hp, gt, M, 1, 8)
+            if two:
+                K.dense_fwd(hs, W1, b1, u); K.dense_fwd(u, W2, b2, out)
+            else:
+                K.dense_fwd(hs, W1, b1, out)
+        timeit(f"gru_fwd + dense unfused M={M} two={two} train={train}", unfused)
