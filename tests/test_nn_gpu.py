@@ -335,7 +335,7 @@ def _leafify(tree):
 
 
 @pytest.mark.parametrize("kind,n,n_obs", [(E.LIDAR_SPREAD, 8, 3), (E.MPE_TARGET, 3, 3), (E.LIDAR_BICYCLE_TARGET, 4, 2),
-                                           (E.MPE_SPREAD, 3, 0)])
+                                           (E.MPE_SPREAD, 3, 0), (E.LIDAR_BICYCLE_TARGET, 16, 8)])   # last: config 5 size
 def test_policy_forward_backward(cuda, kind, n, n_obs):
     from dgppo_amd import nets, ops_nn as K_
     n_env, T_ = 4, 16
