@@ -580,8 +580,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
     }
   }
   STAMP(4);
-  // ---- P2: all n_obs*4 segment tests of (agent, this lane's ray), straight-line (reference arithmetic,
-  //          obstacle.py:97-105; validity without divisions, see the generic kernel; one pipelined division per segment)
+  // ---- P2: all n_obs*4 segment tests of (agent, this lane's ray) (reference arithmetic, obstacle.py:97-105).  Per
+  //      obstacle the 4 segments are unrolled: one batch of LDS reads, validity without divisions (see the generic
+  //      kernel), one division per segment only when some lane of the wave hits it.  det == 0 / NaN (ray parallel to an
+  //      edge: the reference then yields NaN or 1e6 through 0*inf) is only FLAGGED in the loop; a flagged lane redoes
+  //      all of its segments afterwards with the literal reference arithmetic (identical results for the segments
+  //      the fast path handles, which is what makes the two paths interchangeable).
   if (do_sense) {
     for (int base = 0; base < NR; base += nt) {
       const int idx = base + tid;
@@ -589,39 +593,60 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
         const int i = idx >> 5;
         const float x1 = s_next[i * SD], y1 = s_next[i * SD + 1];
         const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
-        const float dx12 = x1 - x2, dy12 = y1 - y2;
+        const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
         float amin = 1e6f, is_in = 0.0f;
-        bool any_nan = false;
+        bool bad = false;
         for (int o = 0; o < no; ++o) is_in = fmaxf(is_in, s_ino[i * no + o]);
-#pragma unroll 4
-        for (int q = 0; q < no * 4; ++q) {
-          const float4 sg = s_seg[q];
-          const float4 as = s_as[i * no * 4 + q];
-          const float ex = sg.z, ey = sg.w, ax = as.x, ay = as.y, na = as.z;
-          const float det0 = dx12 * ey - dy12 * ex;
-          const float nb = (-dy12) * ax + dx12 * ay;
-          // flip both numerators by the sign of det: (na/det, nb/det) == (na'/|det|, nb'/|det|), exactly
-          const uint32_t sb = __float_as_uint(det0) & 0x80000000u;
-          const float naf = __uint_as_float(__float_as_uint(na) ^ sb), nbf = __uint_as_float(__float_as_uint(nb) ^ sb);
-          const float adet = __builtin_amdgcn_fmed3f(fabsf(det0), 1e-7f, 1e7f);      // clip(|det|, 1e-7, 1e7)
-          // 0 <= q <= 1 for both quotients  <=>  0 <= min(na', nb') and max(na', nb') <= |det|   (-0 >= 0 holds, like -0/d >= 0)
-          const bool valid = (fminf(naf, nbf) >= 0.0f) && (fmaxf(naf, nbf) <= adet);
-          float al = 1e6f;
-          if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {       // wave-uniform: skip the division when no lane hits
-            const float qa = naf / adet + 0.0f;                   // v*alpha + (1-v)*1e6 with v = 1 (turns -0 into +0)
-            al = valid ? qa : 1e6f;
+        for (int o = 0; o < no; ++o) {
+          float4 sg[4], as[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { sg[m] = s_seg[o * 4 + m]; as[m] = s_as[(i * no + o) * 4 + m]; }
+          float naf[4], adet[4];
+          bool valid[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float det0 = dx12 * sg[m].w - dy12 * sg[m].z;
+            const float nb = ndy12 * as[m].x + dx12 * as[m].y;
+            // flip both numerators by the sign of det: (na/det, nb/det) == (na'/|det|, nb'/|det|), exactly
+            const uint32_t sb = __float_as_uint(det0) & 0x80000000u;
+            naf[m] = __uint_as_float(__float_as_uint(as[m].z) ^ sb);
+            const float nbf = __uint_as_float(__float_as_uint(nb) ^ sb);
+            adet[m] = __builtin_amdgcn_fmed3f(fabsf(det0), 1e-7f, 1e7f);      // clip(|det|, 1e-7, 1e7)
+            float mn, mx;                  // raw min / max: operands are never signalling NaNs that would need quieting
+            asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(naf[m]), "v"(nbf));
+            asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(naf[m]), "v"(nbf));
+            // 0 <= q <= 1 for both quotients  <=>  0 <= min(na', nb') and max(na', nb') <= |det|   (-0 >= 0 holds, like -0/d >= 0)
+            valid[m] = (mn >= 0.0f) && (mx <= adet[m]);
+            bad = bad || !(det0 != 0.0f);                                      // zero or NaN
           }
-          if (!(det0 != 0.0f) || det0 != det0) {  // det = sign(det0)*clip(|det0|) = 0 or NaN: literal reference arithmetic
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            if (__builtin_amdgcn_ballot_w64(valid[m]) != 0ull) {              // wave-uniform: skip the division when no lane hits
+              const float qa = naf[m] / adet[m] + 0.0f;                       // v*alpha + (1-v)*1e6 with v = 1 (turns -0 into +0)
+              const float al = valid[m] ? qa : 1e6f;
+              asm("v_min_f32 %0, %1, %2" : "=v"(amin) : "v"(amin), "v"(al));
+            }
+          }
+        }
+        float ar = amin;
+        if (bad) {                         // literal reference arithmetic for every segment of this lane
+          float lmin = 1e6f;
+          bool any_nan = false;
+          for (int q = 0; q < no * 4; ++q) {
+            const float4 sgq = s_seg[q];
+            const float4 asq = s_as[i * no * 4 + q];
+            const float det0 = dx12 * sgq.w - dy12 * sgq.z;
+            const float nb = ndy12 * asq.x + dx12 * asq.y;
             const float sgn = (det0 > 0.0f) ? 1.0f : ((det0 < 0.0f) ? -1.0f : det0);
             const float dz = sgn * fminf(fmaxf(fabsf(det0), 1e-7f), 1e7f);
-            const float aq = na / dz, bq = nb / dz;
+            const float aq = asq.z / dz, bq = nb / dz;
             const float v = ((aq <= 1.0f) && (aq >= 0.0f) && (bq <= 1.0f) && (bq >= 0.0f)) ? 1.0f : 0.0f;
-            al = v * aq + (1.0f - v) * 1e6f;
+            const float al = v * aq + (1.0f - v) * 1e6f;
+            any_nan = any_nan || (al != al);
+            lmin = fminf(lmin, al);
           }
-          any_nan = any_nan || (al != al);
-          amin = fminf(amin, al);
+          ar = any_nan ? __builtin_nanf("") : lmin;
         }
-        float ar = any_nan ? __builtin_nanf("") : amin;
         ar = ar * (1.0f - is_in);
         // sort key: float bits (alphas are >= +0), NaN -> max
         reinterpret_cast<uint32_t*>(s_row)[idx] = (ar != ar) ? 0xFFFFFFFFu : __float_as_uint(ar);

@@ -38,6 +38,6 @@ for t in range(2):
         ok &= np.array_equal(v.cpu().numpy(), want["graph"][k])
     a_np, h_np = nx.cpu().numpy(), nh.cpu().numpy()
 print("parity bit-exact:", ok)
-for Bn in (4096, 16384):
+for Bn in ([int(x) for x in os.environ["SIZES"].split(",")] if "SIZES" in os.environ else (4096, 16384)):
     r = bench.roofline_env_kernel(cfg, dev, Bn, iters=100)
     print(Bn, json.dumps({k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in r.items()}))
