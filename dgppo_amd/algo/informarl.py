@@ -1,0 +1,89 @@
+"""InforMARL (the reference's PPO baseline, dgppo/algo/informarl.py:27-457) on the same HIP engine: graph-transformer
+actor + cost critic Vl, no constraint-value network.  The stage cost is -reward + cost_weight * sum(max(cost, 0))
+(informarl.py:329), the advantage the per-env normalised -(Ql - Vl) (informarl.py:334-336); Vl and policy updates are the
+ones DGPPO inherits (informarl.py:357-457).  SURVEY §8f rank 3."""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .. import engine as EN
+from .. import init as INIT
+from .. import nets
+from .base import Algorithm
+from .dgppo import DGPPO
+
+
+class InforMARL(DGPPO):
+    def __init__(self, env, node_dim: int, edge_dim: int, state_dim: int, action_dim: int, n_agents: int,
+                 cost_weight: float = 0.0, actor_gnn_layers: int = 2, Vl_gnn_layers: int = 2, gamma: float = 0.99,
+                 lr_actor: float = 3e-4, lr_Vl: float = 1e-3, batch_size: int = 8192, epoch_ppo: int = 1,
+                 clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2, max_grad_norm: float = 2.0,
+                 seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16, use_lstm: bool = False,
+                 cost_schedule: bool = False, train_steps: int = 1e5, allreduce=None, **kwargs):
+        Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
+        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
+            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1")
+        assert node_dim == env.node_dim and action_dim == 2
+        self.state_dim, self.seed = state_dim, seed
+        self.epoch_ppo, self.use_rnn, self.rnn_layers, self.use_lstm = epoch_ppo, use_rnn, rnn_layers, use_lstm
+        self.hp = EN.Hyper(gamma=gamma, gae_lambda=gae_lambda, clip_eps=clip_eps, coef_ent=coef_ent,
+                           max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, batch_size=batch_size,
+                           rnn_step=rnn_step, train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers,
+                           Vl_gnn_layers=Vl_gnn_layers, cost_weight=cost_weight, cost_schedule=cost_schedule)
+        self.device = env.device
+        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce,
+                                use_graphs=True, multi_stream=True, algo="informarl")
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
+        self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self._rng = np.random.default_rng([seed, 99])
+        self._single = nets.Arena(self.device)
+
+    @property
+    def config(self) -> dict:          # informarl.py:200-221
+        hp = self.hp
+        return {"cost_weight": hp.cost_weight, "actor_gnn_layers": hp.actor_gnn_layers, "Vl_gnn_layers": hp.Vl_gnn_layers,
+                "gamma": hp.gamma, "lr_actor": hp.lr_actor, "lr_Vl": hp.lr_Vl, "batch_size": hp.batch_size,
+                "epoch_ppo": self.epoch_ppo, "clip_eps": hp.clip_eps, "gae_lambda": hp.gae_lambda, "coef_ent": hp.coef_ent,
+                "max_grad_norm": hp.max_grad_norm, "seed": self.seed, "use_rnn": self.use_rnn, "rnn_layers": self.rnn_layers,
+                "rnn_step": hp.rnn_step, "use_lstm": self.use_lstm, "cost_schedule": hp.cost_schedule}
+
+    @property
+    def params(self):
+        e = self.engine
+        return {"policy": e.policy.to_tree(), "Vl": e.Vl.to_tree()}
+
+    def collect(self, params, keys):
+        """one stochastic rollout per key (informarl.py:254-256); no deterministic companion rollout"""
+        self._maybe_load(params)
+        ro = self.engine.rollout(self._seeds(keys), True, noise_seed=int(self._rng.integers(1, 2 ** 62)))
+        return self._wrap(ro)
+
+    def update(self, rollout, step: int) -> dict:
+        ro = self._last_rollouts.pop(id(rollout.actions), None)
+        if ro is None:
+            raise ValueError("update() needs a Rollout produced by this algo's collect()")
+        self._last_rollouts.clear()
+        perm = np.arange(ro.B)
+        np.random.shuffle(perm)                              # host np.random like the reference (informarl.py:270-271)
+        return self.engine.update(ro, None, int(step), perm)
+
+    # checkpoints: {dir}/{step}/{actor,Vl}.pkl (informarl.py:459-470)
+    def save(self, save_dir: str, step: int):
+        model_dir = os.path.join(save_dir, str(step))
+        os.makedirs(model_dir, exist_ok=True)
+        p = self.params
+        for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl")):
+            with open(os.path.join(model_dir, fname), "wb") as f:
+                pickle.dump(p[key], f)
+
+    def load(self, load_dir: str, step: int):
+        path = os.path.join(load_dir, str(step))
+        for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl")):
+            with open(os.path.join(path, fname), "rb") as f:   # files written by save() above (our own pickles)
+                self.engine.nets[key].load_tree(pickle.load(f))

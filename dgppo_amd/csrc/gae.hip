@@ -201,7 +201,7 @@ __global__ void adv_kernel(AdvArgs a) {
   const int T = a.T, n = a.n, nh = a.nh;
   const float* Ql = a.Ql + (size_t)b * T;
   const float* Vl = a.Vl + (size_t)b * (T + 1);
-  const float* Vh = a.Vh + (size_t)b * (T + 1) * n * nh;
+  const float* Vh = a.Vh ? a.Vh + (size_t)b * (T + 1) * n * nh : nullptr;
   float acc = 0.0f;
   for (int t = tid; t < T; t += nt) acc += Ql[t] - Vl[t];
   red[tid] = acc;
@@ -224,7 +224,7 @@ __global__ void adv_kernel(AdvArgs a) {
     const float al = ((Ql[t] - Vl[t]) - mean) / denom;
     bool safe = true;
     float amax = 0.0f;
-    for (int h = 0; h < nh; ++h) {
+    for (int h = 0; a.Vh != nullptr && h < nh; ++h) {       // Vh == NULL: plain normalised advantage (InforMARL)
       const float v0 = Vh[((size_t)t * n + ag) * nh + h], v1 = Vh[((size_t)(t + 1) * n + ag) * nh + h];
       const float deriv = (v1 - v0) * a.inv_dt + a.alpha * v0;
       const float ac = fmaxf(deriv + a.cbf_eps, 0.0f);
@@ -246,9 +246,36 @@ extern "C" int32_t dgppo_advantage(const float* Ql, const float* Vl, const float
                                    int32_t n, int32_t nh, void* stream) {
   DGPPO_REQUIRE(B >= 0 && T >= 1 && n >= 1 && nh >= 1, "advantage: bad sizes");
   if (B == 0) return 0;
-  DGPPO_REQUIRE(Ql && Vl && Vh && adv && stats, "advantage: NULL operand");
+  DGPPO_REQUIRE(Ql && Vl && adv && stats, "advantage: NULL operand");   // Vh may be NULL (no CBF terms)
   AdvArgs a{Ql, Vl, Vh, adv, stats, B, T, n, nh, 1.0f / dt, alpha, cbf_eps, cbf_weight};
   hipLaunchKernelGGL(adv_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// InforMARL's stage cost (dgppo/algo/informarl.py:329): l = -reward + w * sum_{agents, components} max(cost, 0), returned as
+// the equivalent reward r' = reward - w * sum(...) so that dgppo_gae (l = -r') applies unchanged.
+__global__ void shaped_reward_kernel(const float* __restrict__ reward, const float* __restrict__ cost, float w,
+                                     float* __restrict__ out, long rows, int n, int nh) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* c = cost + r * n * nh;
+  float tot = 0.0f;
+  for (int i = 0; i < n; ++i) {                    // .sum(axis=-1).sum(axis=-1): components first, then agents
+    float si = 0.0f;
+    for (int h = 0; h < nh; ++h) si += fmaxf(c[i * nh + h], 0.0f);
+    tot += si;
+  }
+  out[r] = reward[r] - w * tot;
+}
+
+extern "C" int32_t dgppo_shaped_reward(const float* reward, const float* cost, float cost_weight, float* out, int64_t rows,
+                                       int32_t n, int32_t nh, void* stream) {
+  DGPPO_REQUIRE(rows >= 0 && n >= 1 && nh >= 1, "shaped_reward: bad sizes");
+  if (rows == 0) return 0;
+  DGPPO_REQUIRE(reward && cost && out, "shaped_reward: NULL operand");
+  hipLaunchKernelGGL(shaped_reward_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reward,
+                     cost, cost_weight, out, (long)rows, n, nh);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

@@ -43,6 +43,8 @@ class Hyper:
     actor_gnn_layers: int = 2
     Vl_gnn_layers: int = 2
     Vh_gnn_layers: int = 1
+    cost_weight: float = 0.0          # InforMARL: weight of sum(max(cost, 0)) in the stage cost (informarl.py:329)
+    cost_schedule: bool = False       # InforMARL: x5 at 50 % and again x5 at 75 % of train_steps (informarl.py:189-198)
 
 
 class RolloutData:
@@ -92,8 +94,10 @@ class OptState:
 class Engine:
     def __init__(self, cfg: N.EnvCfg, hyper: Hyper, device, T: int = 128,
                  allreduce: Optional[Callable[[torch.Tensor], None]] = None, prepass_graphs: int = 1 << 16,
-                 use_graphs: bool = False, multi_stream: bool = False):
+                 use_graphs: bool = False, multi_stream: bool = False, algo: str = "dgppo"):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
+        assert algo in ("dgppo", "informarl"), algo
+        self.algo = algo                # "informarl": no constraint-value network, no deterministic rollout (informarl.py)
         # HIP-graph replay of the launch-bound rollout loop (18 small kernels per env step).  Opt-in because the record
         # buffers then belong to the engine: a RolloutData stays valid only until the next rollout of the same kind.
         self.use_graphs = use_graphs and os.environ.get("DGPPO_HIPGRAPH", "1") != "0"
@@ -104,7 +108,7 @@ class Engine:
         self.n_cost = 2
         self.policy = nets.Net("policy", cfg, hyper.actor_gnn_layers, 2, device)
         self.Vl = nets.Net("Vl", cfg, hyper.Vl_gnn_layers, 1, device)
-        self.Vh = nets.Net("Vh", cfg, hyper.Vh_gnn_layers, self.n_cost, device)
+        self.Vh = nets.Net("Vh", cfg, hyper.Vh_gnn_layers, self.n_cost, device) if algo == "dgppo" else None
         self.opt = {k: OptState(net.layout.size, device) for k, net in self.nets.items()}
         self.arena = nets.Arena(device)
         self.allreduce = allreduce
@@ -119,7 +123,10 @@ class Engine:
 
     @property
     def nets(self) -> Dict[str, nets.Net]:
-        return {"policy": self.policy, "Vl": self.Vl, "Vh": self.Vh}
+        d = {"policy": self.policy, "Vl": self.Vl}
+        if self.Vh is not None:
+            d["Vh"] = self.Vh
+        return d
 
     def set_entropy_noise(self, seed: int):
         OE.randn(seed, 0, self.eps_hat.view(-1))
@@ -244,12 +251,12 @@ class Engine:
         f.compute(agent, T1 * n * sd, n * sd, goal, obst, hits, T1 * n * cfg.top_k * 2, n * cfg.top_k * 2, env_ids, Eb, n_time)
         return f
 
-    def values_prepass(self, ro: RolloutData, want_Vl: bool):
+    def values_prepass(self, ro: RolloutData, want_Vl: bool, want_Vh: bool = True):
         """-> Vl [B,T+1] (or None), Vh [B,T+1,n,nh] of one rollout, with the reference's carry conventions."""
         cfg, T, B = self.cfg, self.T, ro.B
         n, nh, H = cfg.n_agents, self.n_cost, nets.HID
         Vl_buf = torch.empty(B, T + 1, device=self.device) if want_Vl else None
-        Vh_buf = torch.empty(B, T + 1, n, nh, device=self.device)
+        Vh_buf = torch.empty(B, T + 1, n, nh, device=self.device) if want_Vh else None
         block = max(1, min(B, self.prepass_graphs // (T + 1)))
         for e0 in range(0, B, block):
             Eb = min(block, B - e0)
@@ -257,6 +264,8 @@ class Engine:
             if want_Vl:
                 act = self.Vl.forward(feats, n_seq=Eb, T=T + 1, h0=None, tag="pre", train=False)
                 Vl_buf[e0:e0 + Eb].copy_(act["v"].view(Eb, T + 1))
+            if not want_Vh:
+                continue
             # final carry: actor GRU on next_graph[-1] from rnn_states[-1] (dgppo.py:222-226)
             fin = self._block_feats("fin", ro, e0, Eb, T, 1)
             h_last = self.arena.get("pre.hlast", Eb * n, H)
@@ -282,6 +291,33 @@ class Engine:
             if step >= int(hp.train_steps * 0.75):
                 w *= 2
         return w
+
+    def cost_weight_at(self, step: int) -> float:
+        hp = self.hp
+        w = hp.cost_weight
+        if hp.cost_schedule:  # optax.piecewise_constant_schedule(init, {0.5*steps: 5, 0.75*steps: 5}) (informarl.py:189-196)
+            if step >= int(hp.train_steps * 0.5):
+                w *= 5
+            if step >= int(hp.train_steps * 0.75):
+                w *= 5
+        return w
+
+    def targets_informarl(self, ro: RolloutData, step: int):
+        """InforMARL (informarl.py:309-336): Vl pass, Dec-OCP GAE with Vh := Vl and the cost-shaped stage cost, advantage
+        = -(Ql - Vl) normalised per env."""
+        cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
+        n, nh, dev = cfg.n_agents, self.n_cost, self.device
+        Vl, _ = self.values_prepass(ro, want_Vl=True, want_Vh=False)
+        Vh = Vl.view(B, T + 1, 1, 1).expand(B, T + 1, n, nh).contiguous()
+        shaped = torch.empty(B, T, device=dev)
+        OA.shaped_reward(ro.rewards, ro.costs, self.cost_weight_at(step), shaped)
+        Qh = torch.empty(B, T, n, nh, device=dev)
+        Ql = torch.empty(B, T, device=dev)
+        OA.gae(ro.costs, shaped, Vh, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh, Ql)
+        adv = torch.empty(B, T, n, device=dev)
+        self.stats.zero_()
+        OA.advantage(Ql, Vl, None, cfg.dt, 0.0, 0.0, 0.0, adv, self.stats[3])
+        return dict(Vl=Vl, Ql=Ql, Qh=Qh, adv=adv)
 
     def _net_streams(self):
         if self._side_streams is None:
@@ -318,13 +354,15 @@ class Engine:
     def update(self, ro: RolloutData, det: RolloutData, step: int, perm: np.ndarray) -> dict:
         cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
         n, nh, H = cfg.n_agents, self.n_cost, nets.HID
+        informarl = self.algo == "informarl"
         ro.finalize()
-        det.finalize()
+        if not informarl:
+            det.finalize()
         assert B * T >= hp.batch_size, "n_env_train * T must be >= batch_size (dgppo.py:153)"
         Eb = hp.batch_size // T
         assert B % Eb == 0 and T % hp.rnn_step == 0, "B % (batch_size // T) == 0 and T % rnn_step == 0 required (SURVEY A.11)"
         C = T // hp.rnn_step
-        tg = self.targets(ro, det, step)
+        tg = self.targets_informarl(ro, step) if informarl else self.targets(ro, det, step)
         idx_all = torch.from_numpy(np.ascontiguousarray(perm.astype(np.int64))).to(self.device)
         n_mb = B // Eb
         G = Eb * T
@@ -338,10 +376,11 @@ class Engine:
             self._mb = mb
             # everything the three updates read is produced on the main stream first
             feats = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=idx32)
-            feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=idx32)
             Ql_mb = tg["Ql"].index_select(0, idx)
-            h0_det = det.rnn_states.index_select(0, idx).view(R, H)
-            Qh_det_mb = tg["Qh_det"].index_select(0, idx).view(R, nh)
+            if not informarl:
+                feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=idx32)
+                h0_det = det.rnn_states.index_select(0, idx).view(R, H)
+                Qh_det_mb = tg["Qh_det"].index_select(0, idx).view(R, nh)
             act_mb = ro.actions.index_select(0, idx).view(R, 2)
             lp_old_mb = ro.log_pis.index_select(0, idx).view(R)
             adv_mb = tg["adv"].index_select(0, idx).view(R)
@@ -373,6 +412,8 @@ class Engine:
                 self.policy.backward(act, dms)
                 self._opt_step("policy", hp.lr_actor)
 
+            if informarl:
+                update_Vh = lambda: None                       # noqa: E731  (no constraint-value network)
             if side is None:
                 update_Vl(); update_Vh(); update_policy()
             else:
@@ -395,13 +436,15 @@ class Engine:
         G, R, nh, B = L["G"], L["R"], L["nh"], L["B"]
         o = {k: self.opt[k].state.cpu().numpy() for k in self.opt}
         pol_loss = s[2, 0] / R - self.hp.coef_ent * s[2, 1] / R
-        return {
+        out = {
             "Vl/loss": float(s[0, 0] / G), "Vl/grad_norm": float(o["Vl"][4]), "Vl/has_nan": float(o["Vl"][5]),
             "Vl/max_target": float(L["Ql_mb"].max()), "Vl/min_target": float(L["Ql_mb"].min()),
-            "Vh/loss_Vh": float(s[1, 0] / (R * nh)), "Vh/grad_Vh_norm": float(o["Vh"][4]),
-            "Vh/grad_Vh_has_nan": float(o["Vh"][5]),
             "policy/loss": float(pol_loss), "policy/grad_norm": float(o["policy"][4]), "policy/has_nan": float(o["policy"][5]),
             "policy/log_pi_min": float(ro.log_pis.min()), "policy/clip_frac": float(s[2, 2] / R),
             "policy/entropy": float(s[2, 1] / R), "policy/total_variation_dist": float(0.5 * s[2, 3] / R),
-            "eval/safe_data": float(s[3, 0] / (B * self.T * self.cfg.n_agents)),
         }
+        if self.algo == "dgppo":       # InforMARL logs only the Vl and policy keys (informarl.py:357-457)
+            out.update({"Vh/loss_Vh": float(s[1, 0] / (R * nh)), "Vh/grad_Vh_norm": float(o["Vh"][4]),
+                        "Vh/grad_Vh_has_nan": float(o["Vh"][5]),
+                        "eval/safe_data": float(s[3, 0] / (B * self.T * self.cfg.n_agents))})
+        return out

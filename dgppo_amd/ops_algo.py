@@ -27,9 +27,24 @@ def gae(costs, rewards, Vh, Vl, lam_pow, gamma: float, gae_lambda: float, Qh, Ql
     N.check(rc, "dgppo_gae")
 
 
+def shaped_reward(reward, cost, cost_weight: float, out):
+    """out = reward - w * sum_{agents, components} max(cost, 0)   (InforMARL's stage cost, informarl.py:329)"""
+    B, T, n, nh = cost.shape
+    N.expect_shape(reward, (B, T), "reward")
+    N.expect_shape(out, (B, T), "out")
+    rc = N.lib().dgppo_shaped_reward(N.ptr(reward), N.ptr(cost), C.c_float(cost_weight), N.ptr(out), C.c_int64(B * T), n, nh,
+                                     N.stream_ptr())
+    N.check(rc, "dgppo_shaped_reward")
+
+
 def advantage(Ql, Vl, Vh, dt, alpha, cbf_eps, cbf_weight, adv, stats):
-    B, T1, n, nh = Vh.shape
-    T = T1 - 1
+    """Vh None: InforMARL's plain normalised advantage (no CBF terms)."""
+    if Vh is None:
+        B, T, n = adv.shape
+        nh = 1
+    else:
+        B, T1, n, nh = Vh.shape
+        T = T1 - 1
     N.expect_shape(Ql, (B, T), "Ql")
     N.expect_shape(Vl, (B, T + 1), "Vl")
     N.expect_shape(adv, (B, T, n), "adv")

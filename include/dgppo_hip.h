@@ -237,10 +237,15 @@ int32_t dgppo_gae(const float* costs, const float* rewards, const float* Vh, con
                   float gamma, float one_minus_gamma, float one_minus_lam, float* Qh, float* Ql, int32_t B, int32_t T,
                   int32_t n, int32_t nh, void* stream);
 /* advantage block (dgppo/algo/dgppo.py:239-259): per-env normalised Ql-Vl, CBF derivative, safe gate, schedule weight
- * -> adv [B,T,n] (already negated); stats[0] += number of safe (t, agent) pairs (eval/safe_data numerator).         */
+ * -> adv [B,T,n] (already negated); stats[0] += number of safe (t, agent) pairs (eval/safe_data numerator).
+ * Vh == NULL: InforMARL's advantage (dgppo/algo/informarl.py:334-336): -(Ql-Vl normalised per env), no CBF terms.    */
 int32_t dgppo_advantage(const float* Ql, const float* Vl, const float* Vh, float dt, float alpha, float cbf_eps,
                         float cbf_weight, float* adv, float* stats, int32_t B, int32_t T, int32_t n, int32_t nh,
                         void* stream);
+/* InforMARL's stage cost l = -reward + w * sum_{agents, components} max(cost, 0) (dgppo/algo/informarl.py:329), as the
+ * equivalent reward out = reward - w * sum(...) for dgppo_gae.  reward/out [rows], cost [rows, n, nh].              */
+int32_t dgppo_shaped_reward(const float* reward, const float* cost, float cost_weight, float* out, int64_t rows,
+                            int32_t n, int32_t nh, void* stream);
 /* compute_norm_and_clip + has_any_nan_or_inf (dgppo/trainer/utils.py:89-118) and optax.apply_if_finite(adam)
  * (dgppo/algo/informarl.py:131-137) on one flat buffer.  state [8] lives on the device:
  * [0..1] scratch, [2] adam count, [3] total steps, [4] last grad norm, [5] last non-finite flag.                   */

@@ -87,3 +87,27 @@ def clip_adam(p, g, m, v, count, lr, max_norm, b1=0.9, b2=0.999, eps=1e-8):
     count += 1
     p = p - lr * (m / (1 - b1 ** count)) / (np.sqrt(v / (1 - b2 ** count)) + eps)
     return p, m, v, count, norm, False
+
+
+def cost_weight_schedule(cost_weight, step, train_steps, enabled=False):
+    """optax.piecewise_constant_schedule(init, {0.5*steps: 5, 0.75*steps: 5}) (dgppo/algo/informarl.py:189-198)."""
+    if not enabled:
+        return cost_weight
+    w = cost_weight
+    if step >= int(train_steps * 0.5):
+        w *= 5
+    if step >= int(train_steps * 0.75):
+        w *= 5
+    return w
+
+
+def informarl_targets(costs, rewards, Vl, gamma, lam, cost_weight):
+    """dgppo/algo/informarl.py:323-336.  costs [B,T,n,nh], rewards [B,T], Vl [B,T+1] -> Ql [B,T], A [B,T,n]."""
+    B, T, n, nh = costs.shape
+    Vh = np.repeat(np.repeat(Vl[:, :, None, None], n, axis=-2), nh, axis=-1).astype(f32)
+    l = (-rewards + f32(cost_weight) * np.maximum(costs, 0.0).sum(axis=-1).sum(axis=-1)).astype(f32)
+    out = [compute_dec_ocp_gae(costs[b], l[b], Vh[b], Vl[b], gamma, lam) for b in range(B)]
+    Ql = np.stack([o[1] for o in out])
+    Al = Ql - Vl[:, :-1]
+    Al = (Al - Al.mean(axis=1, keepdims=True)) / (Al.std(axis=1, keepdims=True) + 1e-8)
+    return Ql.astype(f32), (-np.repeat(Al[:, :, None], n, axis=-1)).astype(f32)

@@ -37,6 +37,26 @@ def _sel(g, b=None, t=None):
     return out
 
 
+def values_Vl(trees, ocfg, ro):
+    """Vl [B,T+1]: scan_Vl over the T graphs + the final value on next_graph[-1] (informarl.py:281-320)."""
+    n = ocfg.n_agents
+    g = graphs_of(ocfg, ro["agent"], ro["goal"], ro["obst"], ro["hits"])
+    B, T1 = ro["agent"].shape[:2]
+    with torch.no_grad():
+        h = torch.zeros(B, 1, 64)
+        vs = []
+        for t in range(T1):
+            v, h = T.value_Vl(trees["Vl"], _sel(g, t=t), h, n)
+            vs.append(v)
+    return torch.stack(vs, 1).numpy()
+
+
+def targets_informarl(trees, ocfg, ro, hp, cost_weight):
+    Vl = values_Vl(trees, ocfg, ro)
+    Ql, adv = A.informarl_targets(ro["costs"], ro["rewards"], Vl, hp["gamma"], hp["gae_lambda"], cost_weight)
+    return dict(Vl=Vl, Ql=Ql, adv=adv)
+
+
 def values(trees, ocfg, ro, stochastic):
     """-> Vl [B,T+1] (stochastic only), Vh [B,T+1,n,nh].  ro: dict of numpy arrays (env-major)."""
     n = ocfg.n_agents
@@ -96,14 +116,15 @@ def minibatch_losses(trees, ocfg, ro, det, tg, idx, hp, eps_hat):
     loss_Vl = (0.5 * (v_pred - torch.from_numpy(tg["Ql"][idx])) ** 2).mean()
     loss_Vl.backward()
     out["Vl/loss"] = float(loss_Vl.detach())
-    # ---- Vh on the deterministic rollout with ITS stored carry
-    gd = graphs_of(ocfg, det["agent"][idx][:, :Tn], sub(det, "goal"), sub(det, "obst"),
-                   None if det["hits"] is None else det["hits"][idx][:, :Tn])
-    flat = {k: v.reshape((Eb * Tn,) + v.shape[2:]) for k, v in gd.items()}
-    vh, _ = T.value_Vh(trees["Vh"], flat, torch.from_numpy(det["rnn_states"][idx]).reshape(Eb * Tn, n, 64), n)
-    loss_Vh = (0.5 * (vh.view(Eb, Tn, n, -1) - torch.from_numpy(tg["Qh_det"][idx])) ** 2).mean()
-    loss_Vh.backward()
-    out["Vh/loss_Vh"] = float(loss_Vh.detach())
+    # ---- Vh on the deterministic rollout with ITS stored carry (DGPPO only: det is None for InforMARL)
+    if det is not None:
+        gd = graphs_of(ocfg, det["agent"][idx][:, :Tn], sub(det, "goal"), sub(det, "obst"),
+                       None if det["hits"] is None else det["hits"][idx][:, :Tn])
+        flat = {k: v.reshape((Eb * Tn,) + v.shape[2:]) for k, v in gd.items()}
+        vh, _ = T.value_Vh(trees["Vh"], flat, torch.from_numpy(det["rnn_states"][idx]).reshape(Eb * Tn, n, 64), n)
+        loss_Vh = (0.5 * (vh.view(Eb, Tn, n, -1) - torch.from_numpy(tg["Qh_det"][idx])) ** 2).mean()
+        loss_Vh.backward()
+        out["Vh/loss_Vh"] = float(loss_Vh.detach())
     # ---- policy
     a_in = chunk(torch.from_numpy(ro["actions"][idx]))
     h = torch.zeros(Eb * C, n, 64)

@@ -182,3 +182,30 @@ def test_test_py_cli_after_train(cuda, tmp_path):
     sout = subprocess.run(tcmd[:-4] + ["--stochastic", "--max-step", "32", "--no-video"], capture_output=True, text=True,
                           timeout=600, cwd=ROOT)
     assert sout.returncode == 0 and "epi: 4, reward:" in sout.stdout, sout.stderr[-2000:]
+
+
+def test_informarl_algo_round_trip(cuda, tmp_path):
+    """make_algo("informarl"): collect / update / save / load / act through the reference's surface (informarl.py)."""
+    from dgppo.algo import make_algo
+    from dgppo.env import make_env
+    env = make_env("LidarSpread", 3, num_obs=1, max_step=16)
+    algo = make_algo(algo="informarl", env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+                     action_dim=env.action_dim, n_agents=env.num_agents, cost_weight=0.5, batch_size=128, rnn_step=8,
+                     train_steps=10, seed=1)
+    assert set(algo.params) == {"policy", "Vl"} and algo.config["cost_weight"] == 0.5 and "Vh_gnn_layers" not in algo.config
+    keys = np.arange(1, 17)
+    before = algo.engine.policy.params.clone()
+    for step in range(2):
+        info = algo.update(algo.collect(None, keys + step), step)
+    assert all(np.isfinite(v) for v in info.values()) and not torch.equal(before, algo.engine.policy.params)
+    assert "Vh/loss_Vh" not in info and "Vl/loss" in info
+    algo.save(str(tmp_path), 7)
+    assert sorted(os.listdir(tmp_path / "7")) == ["Vl.pkl", "actor.pkl"]
+    algo2 = make_algo(algo="informarl", env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+                      action_dim=env.action_dim, n_agents=env.num_agents, batch_size=128, rnn_step=8, train_steps=10, seed=2)
+    algo2.load(str(tmp_path), 7)
+    assert torch.equal(algo2.engine.policy.params, algo.engine.policy.params)
+    g = env.reset(5)
+    a1, _ = algo.act(g, algo.init_rnn_state)
+    a2, _ = algo2.act(g, algo2.init_rnn_state)
+    assert torch.equal(a1, a2)

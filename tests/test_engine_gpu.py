@@ -178,3 +178,53 @@ def test_multi_stream_update_equals_single_stream(cuda):
         assert err <= 2e-5 * max(1.0, float(pa.abs().max())), f"{name}: parameters differ by {err:.3e}"
     for k in ("Vl/loss", "Vh/loss_Vh", "policy/loss", "policy/entropy"):
         assert abs(infos[0][k] - infos[1][k]) <= 1e-4 * max(1.0, abs(infos[0][k])), k
+
+
+def test_informarl_targets_and_gradients(cuda):
+    """Engine(algo="informarl"): Vl pass, shaped stage cost, Dec-OCP GAE with Vh := Vl, normalised
+    advantage and the first minibatch's Vl / policy gradients against the oracle; cost-weight schedule x5 past 50 %."""
+    from dgppo_amd import engine as EN, init
+    from oracle import algo_ref as A
+    kind, n, n_obs, B, T_, rs, bs = "LidarSpread", 3, 2, 4, 8, 4, 16
+    cfg, ocfg, hp0, eng0, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs)
+    hp = EN.Hyper(batch_size=bs, rnn_step=rs, train_steps=100, cost_weight=0.3, cost_schedule=True)
+    eng = EN.Engine(cfg, hp, cuda, T=T_, algo="informarl")
+    assert set(eng.nets) == {"policy", "Vl"}
+    for k, net in eng.nets.items():
+        net.load_tree(trees[k])
+    eng.set_entropy_noise(77)
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    ro = eng.rollout(seeds, True, noise_seed=3).finalize()
+    step = 60
+    w = eng.cost_weight_at(step)
+    assert w == pytest.approx(1.5) and A.cost_weight_schedule(0.3, step, 100, True) == pytest.approx(1.5)
+    tg = eng.targets_informarl(ro, step)
+    r = _np_rollout(ro)
+    hpd = dict(gamma=hp.gamma, gae_lambda=hp.gae_lambda, rnn_step=rs, clip_eps=hp.clip_eps, coef_ent=hp.coef_ent)
+    leaf = {k: T.tree_map(lambda t: t.clone().requires_grad_(), trees[k]) for k in ("policy", "Vl")}
+    wt = R.targets_informarl(leaf, ocfg, r, hpd, w)
+    np.testing.assert_allclose(tg["Vl"].cpu().numpy(), wt["Vl"], atol=2e-5)
+    np.testing.assert_allclose(tg["Ql"].cpu().numpy(), wt["Ql"], atol=5e-5)
+    np.testing.assert_allclose(tg["adv"].cpu().numpy(), wt["adv"], atol=2e-3)       # standardised: error / std of 8 samples
+    perm = np.array([2, 0, 3, 1])
+    grads = {}
+
+    def hook(name, net, mb):
+        if mb == 0:
+            grads[name] = net.to_tree(net.grads)
+    eng.grad_hook = hook
+    Eb = bs // T_
+    tg_np = {k: v.cpu().numpy() for k, v in tg.items()}
+    want = R.minibatch_losses(leaf, ocfg, r, None, tg_np, perm[:Eb], hpd, eng.eps_hat.cpu())
+    info = eng.update(ro, None, step, perm)
+    assert set(grads) == {"Vl", "policy"} and "Vh/loss_Vh" not in info and "Vh/loss_Vh" not in want
+    for name in ("Vl", "policy"):
+        wg = dict(T.tree_leaves(T.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), leaf[name])))
+        gt = dict(T.tree_leaves(T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), grads[name])))
+        scale = max(float(v.abs().max()) for v in wg.values())
+        for k in wg:
+            err = float((gt[k].double() - wg[k].double()).abs().max())
+            assert err <= 5e-5 * max(scale, 1e-3), f"{name} grad {k}: err {err:.3e} scale {scale:.3e}"
+    for k in ("Vl/loss", "Vl/grad_norm", "policy/loss", "policy/entropy", "policy/clip_frac"):
+        assert k in info and np.isfinite(info[k]), k
+    assert float(eng.opt["policy"].state[2]) == B // Eb

@@ -83,3 +83,39 @@ def test_adam_three_steps_hand_calculation():
     # non-finite gradient: apply_if_finite skips the step and leaves the inner state untouched
     p3, m3, v3, c3, _, bad = A.clip_adam(p2, np.array([np.nan, 1.0]), m2, v2, c2, lr, 2.0)
     assert bad and c3 == c2 and np.array_equal(p3, p2) and np.array_equal(m3, m2)
+
+
+def test_informarl_targets_known_answers():
+    """InforMARL targets (informarl.py:323-336).  (1) the shaped stage cost; (2) with costs far below zero the constraint
+    never binds and Ql is the textbook GAE(lambda) return of l; (3) the advantage is -(Ql - Vl) standardised per env
+    (population std) and broadcast over agents; (4) the x5 / x25 cost-weight schedule."""
+    from oracle import algo_ref as A
+    rng = np.random.default_rng(3)
+    B, T, n, nh = 3, 12, 4, 2
+    gamma, lam, w = 0.99, 0.95, 0.7
+    rewards = rng.normal(size=(B, T)).astype(np.float32)
+    Vl = rng.normal(size=(B, T + 1)).astype(np.float32)
+    costs = rng.normal(size=(B, T, n, nh)).astype(np.float32) - 50.0          # never binding
+    Ql0, adv0 = A.informarl_targets(costs, rewards, Vl, gamma, lam, w)
+    # all costs negative: max(cost, 0) = 0, l = -reward; textbook recursion A_t = delta_t + gamma*lam*A_{t+1}
+    l = -rewards
+    want = np.zeros((B, T))
+    for b in range(B):
+        a_next = 0.0
+        for t in reversed(range(T)):
+            delta = l[b, t] + gamma * Vl[b, t + 1] - Vl[b, t]
+            a_next = delta + gamma * lam * a_next
+            want[b, t] = a_next + Vl[b, t]
+    np.testing.assert_allclose(Ql0, want, rtol=2e-5, atol=2e-5)
+    Al = want - Vl[:, :-1]
+    Aw = -(Al - Al.mean(1, keepdims=True)) / (Al.std(1, keepdims=True) + 1e-8)
+    np.testing.assert_allclose(adv0, np.repeat(Aw[:, :, None], n, -1), rtol=2e-4, atol=2e-4)
+    assert adv0.shape == (B, T, n) and np.allclose(adv0[..., 0], adv0[..., 3])
+    # positive costs enter the stage cost with weight w: shifting one (t, agent, component) by +c raises l_t by w*c only
+    costs2 = costs.copy()
+    costs2[:, 5, 2, 1] = 3.0                                                  # still <= the running max structure? check l only
+    l2 = -rewards + w * np.maximum(costs2, 0).sum(-1).sum(-1)
+    assert np.allclose(l2[:, 5] - l[:, 5], w * 3.0, atol=1e-6) and np.allclose(np.delete(l2, 5, 1), np.delete(l, 5, 1))
+    # schedule
+    assert A.cost_weight_schedule(0.5, 10, 100, enabled=False) == 0.5
+    assert [A.cost_weight_schedule(0.5, s, 100, enabled=True) for s in (0, 49, 50, 74, 75, 99)] == [0.5, 0.5, 2.5, 2.5, 12.5, 12.5]
