@@ -87,3 +87,40 @@ class InforMARL(DGPPO):
         for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl")):
             with open(os.path.join(path, fname), "rb") as f:   # files written by save() above (our own pickles)
                 self.engine.nets[key].load_tree(pickle.load(f))
+
+
+class HCBFCRPO(InforMARL):
+    """DGPPO with a hand-crafted CBF (dgppo/algo/hcbfcrpo.py:21-205): Vh := env.get_cost(graph); the actor and Vl as in
+    DGPPO, no constraint-value network."""
+
+    def __init__(self, env, node_dim: int, edge_dim: int, state_dim: int, action_dim: int, n_agents: int,
+                 actor_gnn_layers: int = 2, Vl_gnn_layers: int = 2, Vh_gnn_layers: int = 1, gamma: float = 0.99,
+                 lr_actor: float = 3e-4, lr_Vl: float = 1e-3, lr_Vh: float = 1e-3, batch_size: int = 8192,
+                 epoch_ppo: int = 1, clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2,
+                 max_grad_norm: float = 2.0, seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16,
+                 use_lstm: bool = False, alpha: float = 10.0, cbf_eps: float = 1e-2, cbf_weight: float = 1.0,
+                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, **kwargs):
+        Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
+        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
+            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1")
+        assert node_dim == env.node_dim and action_dim == 2
+        self.state_dim, self.seed = state_dim, seed
+        self.epoch_ppo, self.use_rnn, self.rnn_layers, self.use_lstm = epoch_ppo, use_rnn, rnn_layers, use_lstm
+        self.hp = EN.Hyper(gamma=gamma, gae_lambda=gae_lambda, clip_eps=clip_eps, coef_ent=coef_ent,
+                           max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
+                           rnn_step=rnn_step, alpha=alpha, cbf_eps=cbf_eps, cbf_weight=cbf_weight, cbf_schedule=cbf_schedule,
+                           train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers, Vl_gnn_layers=Vl_gnn_layers,
+                           Vh_gnn_layers=Vh_gnn_layers)
+        self.device = env.device
+        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce,
+                                use_graphs=True, multi_stream=True, algo="hcbfcrpo")
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
+        self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self._rng = np.random.default_rng([seed, 99])
+        self._single = nets.Arena(self.device)
+
+    @property
+    def config(self) -> dict:          # the DGPPO config keys (hcbfcrpo.py inherits dgppo.py's property)
+        return DGPPO.config.fget(self)

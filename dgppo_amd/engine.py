@@ -96,8 +96,9 @@ class Engine:
                  allreduce: Optional[Callable[[torch.Tensor], None]] = None, prepass_graphs: int = 1 << 16,
                  use_graphs: bool = False, multi_stream: bool = False, algo: str = "dgppo"):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
-        assert algo in ("dgppo", "informarl"), algo
-        self.algo = algo                # "informarl": no constraint-value network, no deterministic rollout (informarl.py)
+        assert algo in ("dgppo", "informarl", "hcbfcrpo"), algo
+        # "informarl" / "hcbfcrpo": no constraint-value network and no deterministic rollout (informarl.py, hcbfcrpo.py)
+        self.algo = algo
         # HIP-graph replay of the launch-bound rollout loop (18 small kernels per env step).  Opt-in because the record
         # buffers then belong to the engine: a RolloutData stays valid only until the next rollout of the same kind.
         self.use_graphs = use_graphs and os.environ.get("DGPPO_HIPGRAPH", "1") != "0"
@@ -302,6 +303,29 @@ class Engine:
                 w *= 5
         return w
 
+    def targets_hcbfcrpo(self, ro: RolloutData, step: int):
+        """HCBFCRPO (hcbfcrpo.py:120-186): DGPPO's targets with the hand-crafted CBF Vh := env.get_cost(graph).  For
+        t < T that is the stored cost (cost is evaluated on the pre-step graph); the final entry is the cost of
+        next_graph[-1], obtained from one more env.step call whose other outputs are discarded."""
+        cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
+        n, nh, dev = cfg.n_agents, self.n_cost, self.device
+        Vl, _ = self.values_prepass(ro, want_Vl=True, want_Vh=False)
+        fin_agent = ro.agent[:, T].contiguous()
+        fin_hits = ro.hits[:, T].contiguous() if ro.has_hits else None
+        fin_cost = torch.empty(B, n, nh, device=dev)
+        scratch_agent = torch.empty_like(fin_agent)
+        OE.env_step(cfg, fin_agent, torch.zeros(B, n, 2, device=dev), ro.goal, ro.obst, fin_hits, self.ray_cos, self.ray_sin,
+                    scratch_agent, torch.empty_like(fin_hits) if fin_hits is not None else None, torch.empty(B, device=dev),
+                    fin_cost, None)
+        Vh = torch.cat([ro.costs, fin_cost[:, None]], dim=1).contiguous()
+        Qh = torch.empty(B, T, n, nh, device=dev)
+        Ql = torch.empty(B, T, device=dev)
+        OA.gae(ro.costs, ro.rewards, Vh, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh, Ql)
+        adv = torch.empty(B, T, n, device=dev)
+        self.stats.zero_()
+        OA.advantage(Ql, Vl, Vh, cfg.dt, hp.alpha, hp.cbf_eps, self.cbf_weight_at(step), adv, self.stats[3])
+        return dict(Vl=Vl, Vh=Vh, Ql=Ql, Qh=Qh, adv=adv)
+
     def targets_informarl(self, ro: RolloutData, step: int):
         """InforMARL (informarl.py:309-336): Vl pass, Dec-OCP GAE with Vh := Vl and the cost-shaped stage cost, advantage
         = -(Ql - Vl) normalised per env."""
@@ -354,7 +378,7 @@ class Engine:
     def update(self, ro: RolloutData, det: RolloutData, step: int, perm: np.ndarray) -> dict:
         cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
         n, nh, H = cfg.n_agents, self.n_cost, nets.HID
-        informarl = self.algo == "informarl"
+        informarl = self.algo != "dgppo"          # both baselines train only Vl and the policy
         ro.finalize()
         if not informarl:
             det.finalize()
@@ -362,7 +386,8 @@ class Engine:
         Eb = hp.batch_size // T
         assert B % Eb == 0 and T % hp.rnn_step == 0, "B % (batch_size // T) == 0 and T % rnn_step == 0 required (SURVEY A.11)"
         C = T // hp.rnn_step
-        tg = self.targets_informarl(ro, step) if informarl else self.targets(ro, det, step)
+        tg = (self.targets_informarl(ro, step) if self.algo == "informarl" else
+              self.targets_hcbfcrpo(ro, step) if self.algo == "hcbfcrpo" else self.targets(ro, det, step))
         idx_all = torch.from_numpy(np.ascontiguousarray(perm.astype(np.int64))).to(self.device)
         n_mb = B // Eb
         G = Eb * T
@@ -445,6 +470,7 @@ class Engine:
         }
         if self.algo == "dgppo":       # InforMARL logs only the Vl and policy keys (informarl.py:357-457)
             out.update({"Vh/loss_Vh": float(s[1, 0] / (R * nh)), "Vh/grad_Vh_norm": float(o["Vh"][4]),
-                        "Vh/grad_Vh_has_nan": float(o["Vh"][5]),
-                        "eval/safe_data": float(s[3, 0] / (B * self.T * self.cfg.n_agents))})
+                        "Vh/grad_Vh_has_nan": float(o["Vh"][5])})
+        if self.algo != "informarl":   # hcbfcrpo.py:204
+            out["eval/safe_data"] = float(s[3, 0] / (B * self.T * self.cfg.n_agents))
         return out

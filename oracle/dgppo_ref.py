@@ -57,6 +57,19 @@ def targets_informarl(trees, ocfg, ro, hp, cost_weight):
     return dict(Vl=Vl, Ql=Ql, adv=adv)
 
 
+def targets_hcbfcrpo(trees, ocfg, ro, hp, cbf_weight):
+    """hcbfcrpo.py:120-186: Vh := env.get_cost(graph) on the T rollout graphs and on next_graph[-1]."""
+    Vl = values_Vl(trees, ocfg, ro)
+    Tn = ro["agent"].shape[1] - 1
+    hits_fin = None if ro["hits"] is None else ro["hits"][:, Tn]
+    fin = E.env_step(ocfg, ro["agent"][:, Tn], ro["goal"], ro["obst"], hits_fin,
+                     np.zeros((ro["agent"].shape[0], ocfg.n_agents, 2), np.float32), E.ray_table(ocfg.n_rays))
+    Vh = np.concatenate([ro["costs"], fin["cost"][:, None]], axis=1).astype(np.float32)
+    Qh, Ql = A.gae_batch(ro["costs"], ro["rewards"], Vh, Vl, hp["gamma"], hp["gae_lambda"])
+    adv, safe = A.advantage(Ql, Vl, Vh, ocfg.dt, hp["alpha"], hp["cbf_eps"], cbf_weight)
+    return dict(Vl=Vl, Vh=Vh, Ql=Ql, Qh=Qh, adv=adv, safe=safe)
+
+
 def values(trees, ocfg, ro, stochastic):
     """-> Vl [B,T+1] (stochastic only), Vh [B,T+1,n,nh].  ro: dict of numpy arrays (env-major)."""
     n = ocfg.n_agents

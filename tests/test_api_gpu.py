@@ -209,3 +209,16 @@ def test_informarl_algo_round_trip(cuda, tmp_path):
     a1, _ = algo.act(g, algo.init_rnn_state)
     a2, _ = algo2.act(g, algo2.init_rnn_state)
     assert torch.equal(a1, a2)
+
+
+def test_hcbfcrpo_algo_runs(cuda):
+    """make_algo("hcbfcrpo") through the reference's surface: two collect/update iterations, DGPPO's config keys."""
+    from dgppo.algo import make_algo
+    from dgppo.env import make_env
+    env = make_env("MPETarget", 3, num_obs=2, max_step=16)
+    algo = make_algo(algo="hcbfcrpo", env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+                     action_dim=env.action_dim, n_agents=env.num_agents, batch_size=128, rnn_step=8, train_steps=10, seed=1)
+    assert set(algo.params) == {"policy", "Vl"} and "cbf_weight" in algo.config and "alpha" in algo.config
+    for step in range(2):
+        info = algo.update(algo.collect(None, np.arange(1, 17) + step), step)
+    assert all(np.isfinite(v) for v in info.values()) and "eval/safe_data" in info and "Vh/loss_Vh" not in info

@@ -228,3 +228,52 @@ def test_informarl_targets_and_gradients(cuda):
     for k in ("Vl/loss", "Vl/grad_norm", "policy/loss", "policy/entropy", "policy/clip_frac"):
         assert k in info and np.isfinite(info[k]), k
     assert float(eng.opt["policy"].state[2]) == B // Eb
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [("LidarSpread", 3, 2), ("MPESpread", 3, 3)])
+def test_hcbfcrpo_targets_and_gradients(cuda, kind, n, n_obs):
+    """Engine(algo="hcbfcrpo"): hand-crafted CBF Vh := get_cost(graph) incl. the final graph, Dec-OCP GAE,
+    DGPPO's advantage merge, Vl / policy gradients of the first minibatch — against the oracle."""
+    from dgppo_amd import engine as EN
+    B, T_, rs, bs = 4, 8, 4, 16
+    cfg, ocfg, hp0, eng0, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs)
+    hp = EN.Hyper(batch_size=bs, rnn_step=rs, train_steps=100)
+    eng = EN.Engine(cfg, hp, cuda, T=T_, algo="hcbfcrpo")
+    for k, net in eng.nets.items():
+        net.load_tree(trees[k])
+    eng.set_entropy_noise(77)
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    ro = eng.rollout(seeds, True, noise_seed=3).finalize()
+    step = 80                                                       # past 75 %: schedule weight x4
+    tg = eng.targets_hcbfcrpo(ro, step)
+    r = _np_rollout(ro)
+    hpd = dict(gamma=hp.gamma, gae_lambda=hp.gae_lambda, alpha=hp.alpha, cbf_eps=hp.cbf_eps, rnn_step=rs,
+               clip_eps=hp.clip_eps, coef_ent=hp.coef_ent)
+    leaf = {k: T.tree_map(lambda t: t.clone().requires_grad_(), trees[k]) for k in ("policy", "Vl")}
+    assert eng.cbf_weight_at(step) == 4.0
+    wt = R.targets_hcbfcrpo(leaf, ocfg, r, hpd, 4.0)
+    np.testing.assert_array_equal(tg["Vh"].cpu().numpy()[:, :T_], r["costs"])            # stored costs ARE get_cost(graph)
+    np.testing.assert_allclose(tg["Vh"].cpu().numpy()[:, T_], wt["Vh"][:, T_], atol=1e-6)   # cost of next_graph[-1]
+    for k in ("Vl", "Ql", "Qh"):
+        np.testing.assert_allclose(tg[k].cpu().numpy(), wt[k], atol=5e-5, err_msg=k)
+    got_adv = tg["adv"].cpu().numpy()
+    assert (np.abs(got_adv - wt["adv"]) > 2e-3 * np.maximum(1, np.abs(wt["adv"]))).mean() < 0.02      # hard safe-gate flips
+    perm = np.array([2, 0, 3, 1])
+    grads = {}
+
+    def hook(name, net, mb):
+        if mb == 0:
+            grads[name] = net.to_tree(net.grads)
+    eng.grad_hook = hook
+    Eb = bs // T_
+    tg_np = {k: v.cpu().numpy() for k, v in tg.items()}
+    R.minibatch_losses(leaf, ocfg, r, None, tg_np, perm[:Eb], hpd, eng.eps_hat.cpu())
+    info = eng.update(ro, None, step, perm)
+    for name in ("Vl", "policy"):
+        wg = dict(T.tree_leaves(T.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), leaf[name])))
+        gt = dict(T.tree_leaves(T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), grads[name])))
+        scale = max(float(v.abs().max()) for v in wg.values())
+        for k in wg:
+            err = float((gt[k].double() - wg[k].double()).abs().max())
+            assert err <= 5e-5 * max(scale, 1e-3), f"{name} grad {k}: err {err:.3e} scale {scale:.3e}"
+    assert "eval/safe_data" in info and "Vh/loss_Vh" not in info and abs(info["eval/safe_data"] - wt["safe"]) < 0.05
