@@ -611,235 +611,6 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
   ASTAMP(6);
 }
 
-// ---- persistent forward --------------------------------------------------------------------------------------------
-// Same math as attn_fwd_kernel, restructured around latency: a workgroup walks graphs g, g + gridDim.x, ...; the NEXT
-// graph's operands are fetched from HBM into registers while the current graph runs, and every barrier inside the loop
-// waits for LDS only (a __syncthreads() would also wait for the prefetch and for the output stores).  Gather, softmax
-// and the scatter of P are one phase: the 8 lanes that own an (agent, head) pair read its logits from their row of s_L,
-// then overwrite that same row with P (DS operations of one wave execute in order, no barrier needed).  Stores of a
-// graph's results are issued after the next graph's registers have been committed to LDS, so that the vmcnt wait in
-// commit() covers loads only.  Per graph: 4 LDS barriers, 2 MFMA phases.
-#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define ATT_PX 6    // prefetch capacity in float4 per lane: node rows, qt rows, edge rows
-#define ATT_PQ 3
-#define ATT_PE 2
-#define ATT_ZT 2    // Z tiles per wave kept in registers
-template <int F>
-__global__ void __launch_bounds__(256) attn_fwd_pers_kernel(AttnArgs a) {
-  extern __shared__ float sm[];
-  const Topo& t = a.t;
-  const AttnDims d = attn_dims(t, F, a.H);
-  constexpr int Fl = F + 1, F4 = F / 4, FT = (F + 15) / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-  const int n = d.n, S = d.S, Ns = d.Ns, H = d.H, Ll = d.Ll, nH = d.nH, RT = d.RT, CT = d.CT;
-  const int Sp = (S + 3) & ~3, Kp = a.Kp, Wd = F + 4, kc = F + H * Wd;
-  float* s_x = sm;
-  float* s_q = s_x + CT * 16 * Fl;
-  float* s_L = s_q + RT * 16 * Fl;
-  float* s_e = sm + (((CT * 16 * Fl + RT * 16 * Fl + RT * 16 * Ll) + 3) & ~3);   // float4-aligned
-  float* s_m = s_e + n * S * 4;
-  float* s_a = s_m + n * S;               // compact [nH][Sp] attention weights
-  const int nA = n * F4, nX = Ns * F4, nXp = CT * 16 * F4, nQ = nH * F4, nQp = RT * 16 * F4, nE = n * S;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 vx[ATT_PX], vq[ATT_PQ], ve[ATT_PE];
-  float vm[ATT_PE];
-
-  auto fetch = [&](int g, int tid) {             // unconditional clamped loads: all in flight together, nothing waits here
-    const float4* xa = reinterpret_cast<const float4*>(a.Xa + (size_t)g * n * F);
-    const float4* xo = reinterpret_cast<const float4*>(a.Xo + (size_t)g * (Ns - n) * F);
-    const float4* q4 = reinterpret_cast<const float4*>(a.qt + (size_t)g * nH * F);
-    const float4* e4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
-    const float* mk = a.emask + (size_t)g * n * S;
-#pragma unroll
-    for (int it = 0; it < ATT_PX; ++it) {
-      int idx = tid + it * 256;
-      idx = idx < nX ? idx : nX - 1;
-      const float4* p = (idx < nA) ? xa + idx : xo + (idx - nA);
-      vx[it] = *p;
-    }
-#pragma unroll
-    for (int it = 0; it < ATT_PQ; ++it) {
-      int idx = tid + it * 256;
-      idx = idx < nQ ? idx : nQ - 1;
-      vq[it] = q4[idx];
-    }
-#pragma unroll
-    for (int it = 0; it < ATT_PE; ++it) {
-      int idx = tid + it * 256;
-      idx = idx < nE ? idx : nE - 1;
-      ve[it] = e4[idx];
-      vm[it] = mk[idx];
-    }
-  };
-  auto commit = [&](int g, int tid) {            // registers -> LDS (zero padding), plus the parts of zcat that are plain copies
-    float* zc = a.zcat + (size_t)g * n * Kp;
-#pragma unroll
-    for (int it = 0; it < ATT_PX; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < nXp) {
-        const int nd = idx / F4, q = idx - nd * F4;
-        const float4 v = (idx < nX) ? vx[it] : z4;
-        put4(s_x + nd * Fl + 4 * q, v);
-        if (idx < nA) *reinterpret_cast<float4*>(zc + nd * Kp + 4 * q) = v;      // direct x_i part
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < ATT_PQ; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < nQp) { const int row = idx / F4, q = idx - row * F4; put4(s_q + row * Fl + 4 * q, (idx < nQ) ? vq[it] : z4); }
-    }
-#pragma unroll
-    for (int it = 0; it < ATT_PE; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < nE) { const float4 ev = ve[it]; reinterpret_cast<float4*>(s_e)[idx] = make_float4(ev.x, ev.y, ev.z, ev.w); s_m[idx] = vm[it]; }
-    }
-    for (int idx = tid; idx < n * (Kp - kc); idx += 256) {                        // constant column and zero padding
-      const int i = idx / (Kp - kc), c = kc + idx - i * (Kp - kc);
-      zc[i * Kp + c] = (c == kc) ? 1.0f : 0.0f;
-    }
-  };
-
-  int g = blockIdx.x;
-  fetch(g, tid);
-  commit(g, tid);
-  __syncthreads();
-  for (; g < a.G; g += gridDim.x) {
-    const int gn = g + gridDim.x;
-    const bool more = gn < a.G;
-    // an opaque copy of the thread index: without it the compiler hoists every address computation of fetch/commit
-    // out of the graph loop and keeps ~70 extra registers live through the MFMA phases
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));
-    const bool st = (g == (int)gridDim.x);   // second graph of workgroup 0 (steady state)
-    if (st) ASTAMP(0);
-    fetch(more ? gn : a.G - 1, tid_o);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- L = Qt * Xs^T : tiles dealt round-robin, all F/4 k-steps of a tile fetched in one LDS round trip ----
-    for (int tile = wave; tile < RT * CT; tile += 4) {
-      const int rt = tile / CT, ct = tile - rt * CT;
-      const float* qa = s_q + (rt * 16 + li) * Fl + lq;
-      const float* xb = s_x + (ct * 16 + li) * Fl + lq;
-      float av[F4], bv[F4];
-#pragma unroll
-      for (int u = 0; u < F4; ++u) { av[u] = qa[4 * u]; bv[u] = xb[4 * u]; }
-      f32x4g acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < F4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_L[(rt * 16 + lq * 4 + r) * Ll + ct * 16 + li] = acc[r];
-    }
-    LDS_BARRIER();
-    if (st) ASTAMP(1);
-    // ---- gather + softmax + edge aggregation + scatter of P, 8 lanes per (agent, head) pair ----
-    float* zc = a.zcat + (size_t)g * n * Kp;
-    float4 ze_out = z4;
-    int ze_off = -1;
-    for (int p0 = 0; p0 < nH; p0 += 32) {
-      const int pair = p0 + (tid >> 3), sub = tid & 7;
-      const bool live = pair < nH;
-      const int i = live ? pair / H : 0, h = live ? pair - (pair / H) * H : 0;
-      float* Lrow = s_L + (live ? pair : 0) * Ll;
-      float l[ATT_SMAX / 8];
-      int nd[ATT_SMAX / 8];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < ATT_SMAX / 8; ++j) {
-        const int sl = sub + 8 * j;
-        const bool ok = live && sl < S;
-        nd[j] = ok ? sender_node(t, i, sl) : 0;
-        const float lv = Lrow[nd[j]];
-        l[j] = (ok && s_m[i * S + (ok ? sl : 0)] != 0.0f) ? lv : -INFINITY;
-        mx = fmaxf(mx, l[j]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 8)); mx = fmaxf(mx, __shfl_xor(mx, 2, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
-      float den = 0.0f;
-#pragma unroll
-      for (int j = 0; j < ATT_SMAX / 8; ++j) {
-        const float ev = (l[j] == -INFINITY) ? 0.0f : expf(l[j] - mx);
-        l[j] = ev;
-        den += ev;
-      }
-      den += __shfl_xor(den, 1, 8); den += __shfl_xor(den, 2, 8); den += __shfl_xor(den, 4, 8);
-      const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
-      if (live) for (int c = sub; c < CT * 16; c += 8) Lrow[c] = 0.0f;            // own row: logits -> zeros -> P
-      float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
-#pragma unroll
-      for (int j = 0; j < ATT_SMAX / 8; ++j) {
-        const int sl = sub + 8 * j;
-        if (live && sl < S) {
-          const float av = l[j] * inv;
-          s_a[pair * Sp + sl] = av;
-          if (av != 0.0f) {   // masked slots may carry 5e5 / NaN edge features: skip, never multiply
-            Lrow[nd[j]] = av;
-            const float4 e = reinterpret_cast<const float4*>(s_e)[i * S + sl];
-            z0 = fmaf(av, e.x, z0); z1 = fmaf(av, e.y, z1); z2 = fmaf(av, e.z, z2); z3 = fmaf(av, e.w, z3);
-          }
-        }
-      }
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { z0 += __shfl_xor(z0, o, 8); z1 += __shfl_xor(z1, o, 8); z2 += __shfl_xor(z2, o, 8); z3 += __shfl_xor(z3, o, 8); }
-      if (live && sub == 0) {
-        if (p0 == 0) { ze_out = make_float4(z0, z1, z2, z3); ze_off = i * Kp + F + h * Wd + F; }   // stored after commit
-        else *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + F) = make_float4(z0, z1, z2, z3);
-      }
-    }
-    LDS_BARRIER();
-    if (st) ASTAMP(2);
-    // ---- Zx = P * Xs : <= ATT_ZT tiles per wave, results stay in registers until after the commit ----
-    f32x4g zacc[ATT_ZT];
-#pragma unroll
-    for (int zt = 0; zt < ATT_ZT; ++zt) {
-      zacc[zt] = f32x4g{0.f, 0.f, 0.f, 0.f};
-      const int tile = wave + 4 * zt;
-      if (tile < RT * FT) {
-        const int rt = tile / FT, ft = tile - rt * FT;
-        const float* pa = s_L + (rt * 16 + li) * Ll + lq;
-        const int col = ft * 16 + li;
-        const float* xb = s_x + lq * Fl + (col < F ? col : 0);
-        for (int k0 = 0; k0 < CT * 4; k0 += 8) {                                 // 8 k-steps per LDS round trip
-          float av[8], bv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int k4 = (k0 + u < CT * 4) ? k0 + u : CT * 4 - 1;
-            av[u] = pa[4 * k4];
-            bv[u] = xb[4 * k4 * Fl];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const bool okk = k0 + u < CT * 4;
-            zacc[zt] = __builtin_amdgcn_mfma_f32_16x16x4f32(okk ? av[u] : 0.0f, (okk && col < F) ? bv[u] : 0.0f, zacc[zt], 0, 0, 0);
-          }
-        }
-      }
-    }
-    LDS_BARRIER();                      // every wave is done with s_x / s_q / s_L of graph g
-    if (st) ASTAMP(3);
-    if (more) commit(gn, tid_o);
-    __builtin_amdgcn_sched_barrier(0);
-    if (st) ASTAMP(4);
-    // ---- stores of graph g ----
-    if (ze_off >= 0) *reinterpret_cast<float4*>(zc + ze_off) = ze_out;
-#pragma unroll
-    for (int zt = 0; zt < ATT_ZT; ++zt) {
-      const int tile = wave + 4 * zt;
-      if (tile < RT * FT) {
-        const int rt = tile / FT, ft = tile - rt * FT, col = ft * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rt * 16 + lq * 4 + r;
-          if (row < nH && col < F) { const int i = row / H, h = row - i * H; zc[i * Kp + F + h * Wd + col] = zacc[zt][r]; }
-        }
-      }
-    }
-    for (int idx = tid; idx < n * S * H; idx += 256) {
-      const int h = idx % H, is = idx / H, i = is / S, sl = is - i * S;
-      a.attn[(size_t)g * n * S * H + idx] = s_a[(i * H + h) * Sp + sl];
-    }
-    LDS_BARRIER();
-    if (st) { ASTAMP(5); ASTAMP(6); }
-  }
-}
-
 // ---- one wave per graph --------------------------------------------------------------------------------------------
 // For the graph sizes DGPPO uses (n*H <= 32 query rows, <= 96 nodes) a whole graph fits one wave: there is no
 // workgroup barrier anywhere, the 4 waves of a workgroup run 4 independent graphs and other waves fill the stalls.
@@ -1509,10 +1280,6 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   const AttnDims d = attn_dims(t, F, H);
   const size_t msmem = attn_mfma_smem(d, false);
   const bool mfma_ok = (F & 3) == 0 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU");
-  // persistent variant: operands of one graph must fit the prefetch registers, Z tiles the per-wave accumulators
-  const bool pers_ok = mfma_ok && (F == 8 || F == 16 || F == 32 || F == 64) && (Kp & 3) == 0 &&
-                       d.CT * 16 * (F / 4) <= ATT_PX * 256 && d.RT * 16 * (F / 4) <= ATT_PQ * 256 &&
-                       t.n * t.S <= ATT_PE * 256 && d.RT * ((F + 15) / 16) <= 4 * ATT_ZT && !getenv("DGPPO_ATTN_V1");
   // one wave per graph when the shape has an instantiation (fragments within the register budget)
   bool launched = false;
   if (mfma_ok && (Kp & 3) == 0 && t.n * H * H < 65536 && !getenv("DGPPO_ATTN_BLOCK")) {
@@ -1522,23 +1289,10 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
     if (F == 8) launched = launch_attn_wave<8>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
   }
-  if (launched) {
-  } else if (pers_ok) {
-    const void* fn = F == 8 ? (const void*)&attn_fwd_pers_kernel<8> : F == 16 ? (const void*)&attn_fwd_pers_kernel<16>
-                   : F == 32 ? (const void*)&attn_fwd_pers_kernel<32> : (const void*)&attn_fwd_pers_kernel<64>;
-    int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, msmem) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    const int grid = G < per_cu * cus ? G : per_cu * cus;
-    if (F == 8) hipLaunchKernelGGL(attn_fwd_pers_kernel<8>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
-    else if (F == 16) hipLaunchKernelGGL(attn_fwd_pers_kernel<16>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
-    else if (F == 32) hipLaunchKernelGGL(attn_fwd_pers_kernel<32>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_pers_kernel<64>, dim3(grid), dim3(256), msmem, (hipStream_t)stream, a);
-  } else if (mfma_ok)
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(attn_fwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
+  if (!launched) {       // workgroup-per-graph fallbacks: MFMA for F % 4 == 0, plain VALU otherwise
+    if (mfma_ok) hipLaunchKernelGGL(attn_fwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
+  }
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
@@ -1568,13 +1322,12 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
     if (F == 8) launched = launch_attn_wave<8>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
   }
-  if (launched) {
+  if (!launched) {       // workgroup-per-graph fallbacks; among them the VALU kernel wins for narrow layers (measured)
+    if ((F & 3) == 0 && F >= 16 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
+      hipLaunchKernelGGL(attn_bwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(attn_bwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
   }
-  // narrow layers (F = 8) are pure latency: there the VALU kernel's shorter dependency chain wins (measured)
-  else if ((F & 3) == 0 && F >= 16 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(attn_bwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

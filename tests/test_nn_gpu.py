@@ -464,7 +464,7 @@ def test_tree_roundtrip_and_param_counts(cuda):
 @pytest.mark.parametrize("F,Kp", [(8, 48), (32, 144), (16, 80)])
 def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
     """dgppo_attn_fwd/bwd dispatch between the one-wave-per-graph kernels (default for F in {8, 32}), the workgroup-per-
-    graph MFMA kernels (persistent and plain) and the VALU kernels.  The default path is pinned to the oracle by the
+    graph MFMA kernels and the VALU kernels.  The default path is pinned to the oracle by the
     network tests below; this pins every fallback to the default path on the same random inputs (masked slots, NaN edge
     features behind the mask).  F = 16 has no wave instantiation: there the MFMA and VALU families are compared."""
     from dgppo_amd import _native as N, ops_nn as K_
@@ -495,8 +495,7 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
         torch.cuda.synchronize()
         return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo)
 
-    families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "block_v1": {"DGPPO_ATTN_BLOCK": "1", "DGPPO_ATTN_V1": "1"},
-                "valu": {"DGPPO_ATTN_VALU": "1"}}
+    families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "valu": {"DGPPO_ATTN_VALU": "1"}}
     outs = {}
     for name, env in families.items():
         for k, v in env.items():
@@ -507,6 +506,6 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
     ref = outs["default"]
     for k, v in ref.items():
         assert torch.isfinite(v).all(), f"default path left non-finite values in {k}"
-    for name in ("block", "block_v1", "valu"):
+    for name in ("block", "valu"):
         for k in ref:
             _close(outs[name][k], ref[k], 2e-5, f"{name}.{k}")
