@@ -1,32 +1,22 @@
-"""Rollout record with the reference's field names (dgppo/trainer/data.py:8-32).  `graph` / `next_graph` are lazy views:
-the engine stores compact records and materialises GraphsTuples with a HIP kernel only when asked."""
+"""The rollout record handed between `algo.collect`, `algo.update` and the trainer.  Field names and order are API: they
+are the reference's (dgppo/trainer/data.py:8-16).  `graph` / `next_graph` are lazy views here — the engine stores compact
+records and materialises GraphsTuples with a HIP kernel only when someone reads them."""
 from __future__ import annotations
 
-from typing import Any, NamedTuple, Optional
+import collections
+
+_FIELDS = ("graph", "actions", "rnn_states", "rewards", "costs", "dones", "log_pis", "next_graph")
 
 
-class Rollout(NamedTuple):
-    graph: Any
-    actions: Any
-    rnn_states: Any
-    rewards: Any
-    costs: Any
-    dones: Any
-    log_pis: Optional[Any]
-    next_graph: Any
+class Rollout(collections.namedtuple("Rollout", _FIELDS)):
+    """[B, T, ...] arrays; `log_pis` may be None (deterministic rollouts)."""
+    __slots__ = ()
 
-    @property
-    def length(self) -> int:
-        return self.rewards.shape[0]
+    def _dim(self, field: str, axis: int) -> int:
+        return int(getattr(self, field).shape[axis])
 
-    @property
-    def time_horizon(self) -> int:
-        return self.rewards.shape[1]
-
-    @property
-    def num_agents(self) -> int:
-        return self.costs.shape[2]
-
-    @property
-    def n_data(self) -> int:
-        return self.length * self.time_horizon
+    # the four size helpers of the reference (data.py:18-32)
+    length = property(lambda self: self._dim("rewards", 0), doc="number of environments B")
+    time_horizon = property(lambda self: self._dim("rewards", 1), doc="steps per environment T")
+    num_agents = property(lambda self: self._dim("costs", 2), doc="agents per environment")
+    n_data = property(lambda self: self._dim("rewards", 0) * self._dim("rewards", 1), doc="B * T")

@@ -58,25 +58,27 @@ def test(args):
     return agg
 
 
+# the reference's flags (test.py:159-189): (names, kind, default); kind is a type name or "flag"
+FLAGS = [
+    (("--path",), "req:str", None), (("--no-video",), "flag", False), (("--epi",), "int", 5), (("--step",), "int", None),
+    (("--obs",), "int", None), (("--stochastic",), "flag", False), (("--full-observation",), "flag", False),
+    (("--debug",), "flag", False), (("--cpu",), "flag", False), (("--max-step",), "int", None), (("--log",), "flag", False),
+    (("-n", "--num-agents"), "int", None), (("--seed",), "int", 1234), (("--env",), "str", None), (("--offset",), "int", 0),
+    (("--dpi",), "int", 100),
+]
+
+
 def main(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--path", type=str, required=True)
-    parser.add_argument("--no-video", action="store_true", default=False)
-    parser.add_argument("--epi", type=int, default=5)
-    parser.add_argument("--step", type=int, default=None)
-    parser.add_argument("--obs", type=int, default=None)
-    parser.add_argument("--stochastic", action="store_true", default=False)
-    parser.add_argument("--full-observation", action="store_true", default=False)
-    parser.add_argument("--debug", action="store_true", default=False)
-    parser.add_argument("--cpu", action="store_true", default=False)
-    parser.add_argument("--max-step", type=int, default=None)
-    parser.add_argument("--log", action="store_true", default=False)
-    parser.add_argument("-n", "--num-agents", type=int, default=None)
-    parser.add_argument("--seed", type=int, default=1234)
-    parser.add_argument("--env", type=str, default=None)
-    parser.add_argument("--offset", type=int, default=0)
-    parser.add_argument("--dpi", type=int, default=100)
-    args = parser.parse_args(argv)
+    types = {"int": int, "str": str}
+    ap = argparse.ArgumentParser(description=__doc__)
+    for names, kind, default in FLAGS:
+        if kind == "flag":
+            ap.add_argument(*names, action="store_true", default=False)
+        elif kind.startswith("req:"):
+            ap.add_argument(*names, type=types[kind[4:]], required=True)
+        else:
+            ap.add_argument(*names, type=types[kind], default=default)
+    args = ap.parse_args(argv)
     if args.cpu:
         raise SystemExit("--cpu: this build has no CPU product path (the HIP library is required)")
     return test(args)

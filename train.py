@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Drop-in for the reference's train.py (same flags and defaults, train.py:133-182) on the MI355X implementation."""
+"""Training entry point of the MI355X build.  The command line is the reference's (train.py:133-182): every flag keeps
+its name, type and default so that existing launch scripts work unchanged; the flag table below is the single source of
+truth for them."""
 import argparse
 import datetime
 import os
@@ -12,89 +14,91 @@ from dgppo.env import make_env
 from dgppo.trainer.trainer import Trainer
 from dgppo.trainer.utils import is_connected
 
+# (flags, kind, default)   kind: a type -> typed option, "flag" -> store_true, "req:<type>" -> required option
+_T = {"int": int, "float": float, "str": str}
+FLAGS = [
+    (("--env",), "req:str", None), (("-n", "--num-agents"), "req:int", None), (("--algo",), "req:str", None),
+    (("--obs",), "req:int", None),
+    (("--seed",), "int", 0), (("--steps",), "int", 200000), (("--name",), "str", None), (("--debug",), "flag", False),
+    (("--cost-weight",), "float", 0.0), (("--n-rays",), "int", 32), (("--full-observation",), "flag", False),
+    (("--clip-eps",), "float", 0.25), (("--lagr-init",), "float", 0.5), (("--lr-lagr",), "float", 1e-7),
+    (("--cbf-weight",), "float", 1.0), (("--cbf-eps",), "float", 1e-2), (("--alpha",), "float", 10.0),
+    (("--no-cbf-schedule",), "flag", False), (("--cost-schedule",), "flag", False), (("--no-rnn",), "flag", False),
+    (("--actor-gnn-layers",), "int", 2), (("--Vl-gnn-layers",), "int", 2), (("--Vh-gnn-layers",), "int", 1),
+    (("--lr-actor",), "float", 3e-4), (("--lr-Vl",), "float", 1e-3), (("--lr-Vh",), "float", 1e-3),
+    (("--rnn-layers",), "int", 1), (("--use-lstm",), "flag", False), (("--coef-ent",), "float", 1e-2),
+    (("--rnn-step",), "int", 16), (("--n-env-train",), "int", 128), (("--batch-size",), "int", 16384),
+    (("--n-env-test",), "int", 32), (("--log-dir",), "str", "./logs"), (("--eval-interval",), "int", 50),
+    (("--eval-epi",), "int", 1), (("--save-interval",), "int", 50),
+]
 
-def train(args):
-    print(f"> Running train.py {args}")
-    if not is_connected():
-        os.environ["WANDB_MODE"] = "offline"
-    np.random.seed(args.seed)
-    if args.debug:
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(description=__doc__)
+    for names, kind, default in FLAGS:
+        if kind == "flag":
+            ap.add_argument(*names, action="store_true", default=False)
+        elif kind.startswith("req:"):
+            ap.add_argument(*names, type=_T[kind[4:]], required=True)
+        else:
+            ap.add_argument(*names, type=_T[kind], default=default)
+    return ap
+
+
+def _unique_run_dir(root: str, seed: int):
+    """{root}/seed{seed}_{MMDDhhmmss}_{4 random capitals}, bumped until it does not exist (train.py:81-93)."""
+    tag = "".join(chr(c) for c in np.random.default_rng().integers(65, 91, size=4))
+    stamp = int(datetime.datetime.now().strftime("%m%d%H%M%S"))
+    while os.path.exists(f"{root}/seed{seed}_{stamp}_{tag}"):
+        stamp += 1
+    return f"{root}/seed{seed}_{stamp}_{tag}", stamp, tag
+
+
+def _algo_kwargs(a, env) -> dict:
+    """what the reference hands to make_algo (train.py:44-77)"""
+    return dict(
+        algo=a.algo, env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+        action_dim=env.action_dim, n_agents=env.num_agents, seed=a.seed, train_steps=a.steps, batch_size=a.batch_size,
+        gamma=0.99, max_grad_norm=2.0, clip_eps=a.clip_eps, coef_ent=a.coef_ent,
+        actor_gnn_layers=a.actor_gnn_layers, Vl_gnn_layers=a.Vl_gnn_layers, Vh_gnn_layers=a.Vh_gnn_layers,
+        lr_actor=a.lr_actor, lr_Vl=a.lr_Vl, lr_Vh=a.lr_Vh,
+        use_rnn=not a.no_rnn, rnn_layers=a.rnn_layers, rnn_step=a.rnn_step, use_lstm=a.use_lstm,
+        alpha=a.alpha, cbf_eps=a.cbf_eps, cbf_weight=a.cbf_weight, cbf_schedule=not a.no_cbf_schedule,
+        cost_weight=a.cost_weight, cost_schedule=a.cost_schedule, lagr_init=a.lagr_init, lr_lagr=a.lr_lagr)
+
+
+def train(a):
+    print(f"> Running train.py {a}")
+    np.random.seed(a.seed)
+    if a.debug:
         os.environ["WANDB_MODE"] = "disabled"
-    mk = lambda: make_env(env_id=args.env, num_agents=args.num_agents, num_obs=args.obs, n_rays=args.n_rays,
-                          full_observation=args.full_observation)
-    env, env_test = mk(), mk()
-    algo = make_algo(
-        algo=args.algo, env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
-        action_dim=env.action_dim, n_agents=env.num_agents, cost_weight=args.cost_weight, cbf_weight=args.cbf_weight,
-        actor_gnn_layers=args.actor_gnn_layers, Vl_gnn_layers=args.Vl_gnn_layers, Vh_gnn_layers=args.Vh_gnn_layers,
-        rnn_layers=args.rnn_layers, lr_actor=args.lr_actor, lr_Vl=args.lr_Vl, lr_Vh=args.lr_Vh, max_grad_norm=2.0,
-        alpha=args.alpha, cbf_eps=args.cbf_eps, seed=args.seed, batch_size=args.batch_size, use_rnn=not args.no_rnn,
-        use_lstm=args.use_lstm, coef_ent=args.coef_ent, rnn_step=args.rnn_step, gamma=0.99, clip_eps=args.clip_eps,
-        lagr_init=args.lagr_init, lr_lagr=args.lr_lagr, train_steps=args.steps, cbf_schedule=not args.no_cbf_schedule,
-        cost_schedule=args.cost_schedule)
-    rng_ = np.random.default_rng()
-    rand_id = "".join([chr(rng_.integers(65, 91)) for _ in range(4)])
-    start_time = int(datetime.datetime.now().strftime("%m%d%H%M%S"))
-    if not args.debug:
-        os.makedirs(f"{args.log_dir}/{args.env}/{args.algo}", exist_ok=True)
-    while os.path.exists(f"{args.log_dir}/{args.env}/{args.algo}/seed{args.seed}_{start_time}_{rand_id}"):
-        start_time += 1
-    log_dir = f"{args.log_dir}/{args.env}/{args.algo}/seed{args.seed}_{start_time}_{rand_id}"
-    run_name = "{}_seed{:03}_{}_{}".format(args.algo, args.seed, start_time, rand_id)
-    if args.name is not None:
-        run_name = "{}_{}_seed{:03}_{}_{}".format(run_name, args.name, args.seed, start_time, rand_id)
-    train_params = {"run_name": run_name, "training_steps": args.steps, "eval_interval": args.eval_interval,
-                    "eval_epi": args.eval_epi, "save_interval": args.save_interval}
-    trainer = Trainer(env=env, env_test=env_test, algo=algo, gamma=0.99, log_dir=log_dir, n_env_train=args.n_env_train,
-                      n_env_test=args.n_env_test, seed=args.seed, params=train_params, save_log=not args.debug)
-    if not args.debug:
+    elif not is_connected():
+        os.environ["WANDB_MODE"] = "offline"
+
+    def new_env():
+        return make_env(env_id=a.env, num_agents=a.num_agents, num_obs=a.obs, n_rays=a.n_rays,
+                        full_observation=a.full_observation)
+
+    env, env_test = new_env(), new_env()
+    algo = make_algo(**_algo_kwargs(a, env))
+
+    root = f"{a.log_dir}/{a.env}/{a.algo}"
+    if not a.debug:
+        os.makedirs(root, exist_ok=True)
+    log_dir, stamp, tag = _unique_run_dir(root, a.seed)
+    run_name = f"{a.algo}_seed{a.seed:03}_{stamp}_{tag}"
+    if a.name is not None:
+        run_name = f"{run_name}_{a.name}_seed{a.seed:03}_{stamp}_{tag}"
+    schedule = {"run_name": run_name, "training_steps": a.steps, "eval_interval": a.eval_interval, "eval_epi": a.eval_epi,
+                "save_interval": a.save_interval}
+    trainer = Trainer(env=env, env_test=env_test, algo=algo, gamma=0.99, log_dir=log_dir, n_env_train=a.n_env_train,
+                      n_env_test=a.n_env_test, seed=a.seed, params=schedule, save_log=not a.debug)
+    if not a.debug:   # plain mappings (the reference dumps the argparse.Namespace object itself; test.py reads both)
         with open(f"{log_dir}/config.yaml", "w") as f:
-            yaml.safe_dump(vars(args), f)
+            yaml.safe_dump(vars(a), f)
             yaml.safe_dump(algo.config, f)
     trainer.train()
 
 
-def main():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--env", type=str, required=True)
-    parser.add_argument("-n", "--num-agents", type=int, required=True)
-    parser.add_argument("--algo", type=str, required=True)
-    parser.add_argument("--obs", type=int, required=True)
-    parser.add_argument("--seed", type=int, default=0)
-    parser.add_argument("--steps", type=int, default=200000)
-    parser.add_argument("--name", type=str, default=None)
-    parser.add_argument("--debug", action="store_true", default=False)
-    parser.add_argument("--cost-weight", type=float, default=0.)
-    parser.add_argument("--n-rays", type=int, default=32)
-    parser.add_argument("--full-observation", action="store_true", default=False)
-    parser.add_argument("--clip-eps", type=float, default=0.25)
-    parser.add_argument("--lagr-init", type=float, default=0.5)
-    parser.add_argument("--lr-lagr", type=float, default=1e-7)
-    parser.add_argument("--cbf-weight", type=float, default=1.0)
-    parser.add_argument("--cbf-eps", type=float, default=1e-2)
-    parser.add_argument("--alpha", type=float, default=10.0)
-    parser.add_argument("--no-cbf-schedule", action="store_true", default=False)
-    parser.add_argument("--cost-schedule", action="store_true", default=False)
-    parser.add_argument("--no-rnn", action="store_true", default=False)
-    parser.add_argument("--actor-gnn-layers", type=int, default=2)
-    parser.add_argument("--Vl-gnn-layers", type=int, default=2)
-    parser.add_argument("--Vh-gnn-layers", type=int, default=1)
-    parser.add_argument("--lr-actor", type=float, default=3e-4)
-    parser.add_argument("--lr-Vl", type=float, default=1e-3)
-    parser.add_argument("--lr-Vh", type=float, default=1e-3)
-    parser.add_argument("--rnn-layers", type=int, default=1)
-    parser.add_argument("--use-lstm", action="store_true", default=False)
-    parser.add_argument("--coef-ent", type=float, default=1e-2)
-    parser.add_argument("--rnn-step", type=int, default=16)
-    parser.add_argument("--n-env-train", type=int, default=128)
-    parser.add_argument("--batch-size", type=int, default=16384)
-    parser.add_argument("--n-env-test", type=int, default=32)
-    parser.add_argument("--log-dir", type=str, default="./logs")
-    parser.add_argument("--eval-interval", type=int, default=50)
-    parser.add_argument("--eval-epi", type=int, default=1)
-    parser.add_argument("--save-interval", type=int, default=50)
-    train(parser.parse_args())
-
-
 if __name__ == "__main__":
-    main()
+    train(build_parser().parse_args())
