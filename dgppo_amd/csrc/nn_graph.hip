@@ -688,6 +688,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
       }
     }
   }
+  // node fragments of the aggregation GEMM and the edge features of this lane's slots.  Narrow layers (F = 8) have the
+  // registers to request them together with the logit fragments — ONE global-memory round trip per graph; for F = 32
+  // that would cost the third wave per SIMD (measured: 122 vs 113 us), so there they are requested after the logit GEMM,
+  // when its fragments are dead, and land while the softmax runs.
+  constexpr bool EARLY = (F <= 8);
+  float bz[KZ][FT];
+  float4 efv[NP][SJ];
+  auto load_late_operands = [&]() {
+#pragma unroll
+    for (int k4 = 0; k4 < KZ; ++k4) {
+      const float* p = xrow(k4 * 4 + lq);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) { const int col = ft * 16 + li; bz[k4][ft] = p[col < F ? col : F - 1]; }
+    }
+    const float* ef = a.efeat + (size_t)g * n * S * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        int sl = sub + 8 * j;
+        sl = sl < S ? sl : S - 1;
+        efv[p][j] = reinterpret_cast<const float4*>(ef)[pi[p] * S + sl];
+      }
+  };
+  if constexpr (EARLY) { load_late_operands(); __builtin_amdgcn_sched_barrier(0); }
   ASTAMP(1);
   // ---- L = Qt Xs^T, one row tile at a time, its column tiles interleaved (independent accumulators) ----
 #pragma unroll
@@ -705,28 +730,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
       for (int r = 0; r < 4; ++r) s_L[(rt * 16 + lq * 4 + r) * Ll + ct * 16 + li] = acc[ct][r];
   }
   ASTAMP(2);
-  // ---- node fragments of the aggregation GEMM: issued now (not earlier: the logit fragments are dead by now), they
-  //      land while the softmax runs ----
-  __builtin_amdgcn_sched_barrier(0);
-  float bz[KZ][FT];
-#pragma unroll
-  for (int k4 = 0; k4 < KZ; ++k4) {
-    const float* p = xrow(k4 * 4 + lq);
-#pragma unroll
-    for (int ft = 0; ft < FT; ++ft) { const int col = ft * 16 + li; bz[k4][ft] = p[col < F ? col : F - 1]; }
-  }
-  float4 efv[NP][SJ];                   // edge features of this lane's slots (consumed at the end of each pass)
-  {
-    const float* ef = a.efeat + (size_t)g * n * S * 4;
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-      for (int j = 0; j < SJ; ++j) {
-        int sl = sub + 8 * j;
-        sl = sl < S ? sl : S - 1;
-        efv[p][j] = reinterpret_cast<const float4*>(ef)[pi[p] * S + sl];
-      }
-  }
+  if constexpr (!EARLY) { __builtin_amdgcn_sched_barrier(0); load_late_operands(); }
   // the parts of zcat that are plain copies: x_i, the constant column, zero padding
   if (lane < n * FQ) *reinterpret_cast<float4*>(zc + (lane / FQ) * Kp + 4 * (lane % FQ)) = xcopy;
   for (int idx = lane + 64; idx < n * FQ; idx += 64)
