@@ -146,7 +146,15 @@ def ptr(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") ->
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr() -> C.c_void_p:
+    """HIP stream the kernels are enqueued on = torch's current stream.  Called once per launch, so it goes through the two
+    C entry points directly; `torch.cuda.current_stream().cuda_stream` costs ~15 us of Python per call (measured)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

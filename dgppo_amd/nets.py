@@ -38,7 +38,7 @@ class Layout:
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         off, shape = self.entries[name]
-        return flat[off:off + int(np.prod(shape))].view(*shape)
+        return flat[off:off + math.prod(shape)].view(shape)
 
 
 def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int) -> Layout:
@@ -81,14 +81,14 @@ class Arena:
         self.generation = 0          # bumped whenever a buffer is re-allocated (moves): captured HIP graphs check it before replay
 
     def get(self, name: str, *shape, dtype=torch.float32, zero=False) -> torch.Tensor:
-        n = int(np.prod(shape))
+        n = math.prod(shape)
         b = self.bufs.get(name)
         if b is None or b.numel() < n or b.dtype != dtype:
             if b is not None:
                 self.generation += 1     # an existing buffer moves: pointers baked into captured graphs are stale
             b = torch.empty(max(n, 1), dtype=dtype, device=self.device)
             self.bufs[name] = b
-        v = b[:n].view(*shape)
+        v = b[:n].view(shape)
         if zero:
             v.zero_()
         return v
@@ -124,6 +124,7 @@ class Net:
         self.params = torch.zeros(self.layout.size, device=device)
         self.grads = torch.zeros(self.layout.size, device=device)
         self.arena = Arena(device)
+        self._views: Dict[tuple, torch.Tensor] = {}
         # per-layer dims: F (true input width), Fp (padded), D, Kp
         self.dims = []
         f = cfg.node_dim
@@ -143,17 +144,25 @@ class Net:
         self.prep_grads = torch.zeros(self.prep_layout.size, device=device)
 
     # ---- parameter access ------------------------------------------------------------------------------------------
+    # views into the flat buffers; the buffers never move (in-place updates only), so the views are built once
+    def _cached(self, kind: str, layout, flat, name):
+        key = (kind, name)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = layout.view(flat, name)
+        return v
+
     def p(self, name):
-        return self.layout.view(self.params, name)
+        return self._cached("p", self.layout, self.params, name)
 
     def g(self, name):
-        return self.layout.view(self.grads, name)
+        return self._cached("g", self.layout, self.grads, name)
 
     def pp(self, name):
-        return self.prep_layout.view(self.prep, name)
+        return self._cached("pp", self.prep_layout, self.prep, name)
 
     def pg(self, name):
-        return self.prep_layout.view(self.prep_grads, name)
+        return self._cached("pg", self.prep_layout, self.prep_grads, name)
 
     def prepare(self):
         """params -> prepared GNN weights (call after every parameter change)."""

@@ -24,7 +24,17 @@ for it in range(4):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     orig = eng.targets
     eng.targets = lambda *a, **k: tg            # reuse: time the minibatch loop alone
+    torch.cuda.synchronize(); t1 = time.perf_counter()
     eng.update(ro, det, it, rng.permutation(B))
+    t_issue = time.perf_counter()          # update() ends with one host sync for the logged scalars (stats.cpu())
     torch.cuda.synchronize(); t2 = time.perf_counter()
     eng.targets = orig
     print(f"iter {it}: targets (pre-passes + 2 GAE + advantage) {1e3 * (t1 - t0):.1f} ms, 32 minibatches {1e3 * (t2 - t1):.1f} ms")
+    if it == 3:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        eng.targets = lambda *a, **k: tg
+        ro2, det2 = eng.rollout_pair(seeds + 9, seeds + 100009, noise_seed=9)
+        ro2.finalize(); det2.finalize(); torch.cuda.synchronize()
+        pr.enable(); eng.update(ro2, det2, it, rng.permutation(B)); pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(14)
