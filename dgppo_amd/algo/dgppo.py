@@ -174,7 +174,13 @@ class DGPPO(Algorithm):
         eng = self.engine
         if env is not None and env is not self._env:
             assert env.cfg.kind == self._env.cfg.kind and env.num_agents == self.n_agents
-        ro = eng.rollout(self._seeds(keys), False)
+        seeds = self._seeds(keys)
+        pend = getattr(self, "_pending_det", None)
+        if pend is not None and pend[1].B == int(seeds.shape[0]):
+            # this rollout reuses the record buffers of the deterministic rollout that collect() prepared for update():
+            # drop the hand-over, update() will produce its own
+            self._pending_det = None
+        ro = eng.rollout(seeds, False)
         return self._wrap(ro, env)
 
     def collect_stochastic(self, keys, env=None) -> Rollout:

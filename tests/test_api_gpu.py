@@ -222,3 +222,20 @@ def test_hcbfcrpo_algo_runs(cuda):
     for step in range(2):
         info = algo.update(algo.collect(None, np.arange(1, 17) + step), step)
     assert all(np.isfinite(v) for v in info.values()) and "eval/safe_data" in info and "Vh/loss_Vh" not in info
+
+
+def test_collect_then_evaluate_then_update_is_safe(cuda):
+    """collect() prepares the deterministic rollout update() needs in engine-owned buffers; a deterministic evaluation of the
+    same batch size in between reuses those buffers, so the hand-over must be dropped and update() must still work."""
+    from dgppo.algo import make_algo
+    from dgppo.env import make_env
+    env = make_env("LidarSpread", 3, num_obs=1, max_step=16)
+    algo = make_algo(algo="dgppo", env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+                     action_dim=env.action_dim, n_agents=env.num_agents, batch_size=128, rnn_step=8, train_steps=10, seed=3)
+    keys = np.arange(1, 17)
+    ro = algo.collect(None, keys)
+    assert algo._pending_det is not None
+    algo.collect_deterministic(keys + 100, env=env)          # same batch size: reuses the (16, deterministic) buffers
+    assert algo._pending_det is None
+    info = algo.update(ro, 0)
+    assert all(np.isfinite(v) for v in info.values())
