@@ -78,16 +78,24 @@ __global__ void gae_kernel(GaeArgs a) {
 // Faster variant for T + 1 <= 256: thread j owns DP row j (its n*nh constraint values + the cost value) in registers,
 // the env's costs / values are staged in LDS once, and Q = sum_j c_j row_j is a workgroup reduction (wave shuffles, then
 // one LDS hop) instead of a serial loop.  Same recurrences; only the summation order of Q differs (fp32, ~1e-7).
+__device__ inline float gae_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+
 template <int AHP>
 __global__ void __launch_bounds__(256) gae_rows_kernel(GaeArgs a) {
   extern __shared__ float sm[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = a.T, AH = a.AH, n = a.n, nh = a.nh;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int T = a.T, AH = a.AH, nh = a.nh;
   float* s_cost = sm;                       // [T][AH]
   float* s_Vh = s_cost + T * AH;            // [T+1][AH]
   float* s_Vl = s_Vh + (T + 1) * AH;        // [T+1]
   float* s_rew = s_Vl + (T + 1);            // [T]
-  float* s_part = s_rew + T;                // [2][4][AHP+1]  per-wave partial sums, double buffered
+  float* s_part = s_rew + T;                // [2][16][AHP+1]  per-16-lane-row partial sums, double buffered
   const float* costs = a.costs + (size_t)b * T * AH;
   const float* Vh = a.Vh + (size_t)b * (T + 1) * AH;
   for (int i = tid; i < T * AH; i += 256) s_cost[i] = costs[i];
@@ -125,21 +133,17 @@ __global__ void __launch_bounds__(256) gae_rows_kernel(GaeArgs a) {
         contrib[ag] = 0.0f;
       }
     }
-    // workgroup reduction of AH + 1 values
+    // workgroup reduction of AH + 1 values: DPP sums inside each 16-lane row (VALU only; a 64-lane __shfl_xor reduction
+    // is 6 LDS-crossbar round trips per value), then the 16 row sums of the workgroup meet in LDS
 #pragma unroll
-    for (int c = 0; c < AHP; ++c) {
-      float v = contrib[c];
+    for (int c = 0; c < AHP; ++c) contrib[c] = gae_row16_sum(contrib[c]);
+    cl = gae_row16_sum(cl);
+    float* part = s_part + (ii & 1) * 16 * (AHP + 1);
+    if ((lane & 15) == 0) {
+      float* dst = part + (tid >> 4) * (AHP + 1);
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-      contrib[c] = v;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) cl += __shfl_xor(cl, o);
-    float* part = s_part + (ii & 1) * 4 * (AHP + 1);
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < AHP; ++c) part[wave * (AHP + 1) + c] = contrib[c];
-      part[wave * (AHP + 1) + AHP] = cl;
+      for (int c = 0; c < AHP; ++c) dst[c] = contrib[c];
+      dst[AHP] = cl;
     }
     // row insertion for the next step (utils.py:53-54)
     if (j == ii + 1) {
@@ -150,7 +154,9 @@ __global__ void __launch_bounds__(256) gae_rows_kernel(GaeArgs a) {
     __syncthreads();
     if (tid <= AH) {
       const int c = (tid < AH) ? tid : AHP;
-      const float q = part[c] + part[(AHP + 1) + c] + part[2 * (AHP + 1) + c] + part[3 * (AHP + 1) + c];
+      float q = 0.0f;
+#pragma unroll
+      for (int rw = 0; rw < 16; ++rw) q += part[rw * (AHP + 1) + c];
       if (tid < AH) a.Qh[((size_t)b * T + t) * AH + tid] = q;
       else a.Ql[(size_t)b * T + t] = q;
     }
@@ -166,7 +172,7 @@ extern "C" int32_t dgppo_gae(const float* costs, const float* rewards, const flo
   GaeArgs a{costs, rewards, Vh, Vl, lam_pow, Qh, Ql, B, T, n * nh, n, nh, gamma, one_minus_gamma, one_minus_lam};
   if (T + 1 <= 256 && a.AH <= 32) {
     const int ahp = a.AH <= 8 ? 8 : (a.AH <= 16 ? 16 : 32);
-    const size_t fsm = sizeof(float) * ((size_t)T * a.AH + (size_t)(T + 1) * a.AH + (T + 1) + T + 2 * 4 * (ahp + 1));
+    const size_t fsm = sizeof(float) * ((size_t)T * a.AH + (size_t)(T + 1) * a.AH + (T + 1) + T + 2 * 16 * (ahp + 1));
     if (fsm <= 64 * 1024) {
       hipStream_t st = (hipStream_t)stream;
       if (ahp == 8) hipLaunchKernelGGL(gae_rows_kernel<8>, dim3(B), dim3(256), fsm, st, a);
