@@ -611,6 +611,25 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
   ASTAMP(6);
 }
 
+// reductions over the 8 lanes that own an (agent, head) pair: DPP moves inside the VALU (quad swaps, then the mirror of
+// the 8-lane half row); every lane of the group ends with the result.  __shfl_xor(width 8) would be 3 LDS-crossbar round
+// trips per reduction.
+template <int CTRL> __device__ inline float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ inline float grp8_sum(float v) {
+  v += dpp_f<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);    // row_half_mirror
+  return v;
+}
+__device__ inline float grp8_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  return v;
+}
+
 // ---- one wave per graph --------------------------------------------------------------------------------------------
 // For the graph sizes DGPPO uses (n*H <= 32 query rows, <= 96 nodes) a whole graph fits one wave: there is no
 // workgroup barrier anywhere, the 4 waves of a workgroup run 4 independent graphs and other waves fill the stalls.
@@ -762,7 +781,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         l[j] = (ok && mkv[p][j] != 0.0f) ? lv : -INFINITY;
         mx = fmaxf(mx, l[j]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 8)); mx = fmaxf(mx, __shfl_xor(mx, 2, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4, 8));
+      mx = grp8_max(mx);
       float den = 0.0f;
 #pragma unroll
       for (int j = 0; j < SJ; ++j) {
@@ -770,7 +789,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         l[j] = ev;
         den += ev;
       }
-      den += __shfl_xor(den, 1, 8); den += __shfl_xor(den, 2, 8); den += __shfl_xor(den, 4, 8);
+      den = grp8_sum(den);
       const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
       if (live) {
 #pragma unroll
@@ -790,8 +809,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
           }
         }
       }
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { z0 += __shfl_xor(z0, o, 8); z1 += __shfl_xor(z1, o, 8); z2 += __shfl_xor(z2, o, 8); z3 += __shfl_xor(z3, o, 8); }
+      z0 = grp8_sum(z0); z1 = grp8_sum(z1); z2 = grp8_sum(z2); z3 = grp8_sum(z3);
       if (live && sub == 0) *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + F) = make_float4(z0, z1, z2, z3);
     }
   }
@@ -967,7 +985,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
       dl[p][j] = dA;
       dot = fmaf(av[p][j], dA, dot);
     }
-    dot += __shfl_xor(dot, 1, 8); dot += __shfl_xor(dot, 2, 8); dot += __shfl_xor(dot, 4, 8);
+    dot = grp8_sum(dot);
 #pragma unroll
     for (int j = 0; j < SJ; ++j) dl[p][j] = av[p][j] * (dl[p][j] - dot);
     if (live) {
@@ -1208,7 +1226,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(AttnArgs a) {
       dA[j] = (live && sl < S) ? s_c[pair * Sp + sl] : 0.0f;
       dot = fmaf(av[j], dA[j], dot);
     }
-    dot += __shfl_xor(dot, 1, 8); dot += __shfl_xor(dot, 2, 8); dot += __shfl_xor(dot, 4, 8);
+    dot = grp8_sum(dot);
 #pragma unroll
     for (int j = 0; j < ATT_SMAX / 8; ++j) {
       const int sl = sub + 8 * j;
