@@ -33,6 +33,7 @@ struct StepArgs {
   dgppo_graph_out g;
   int has_graph;
   int mode;
+  uint32_t rcp_n, rcp_k, rcp_no, rcp_no4;   // ceil(2^32 / d) for the index divisions of lidar_step_kernel (fdiv below)
   int B;
 };
 
@@ -437,6 +438,11 @@ extern "C" int32_t dgppo_debug_stamps(unsigned long long* out) {
 #endif
 #define MISS_BITS 0x49742400u  // bits of 1e6f
 
+// x / d for 0 <= x < 2^16 and 1 <= d < 2^16 with rcp = ceil(2^32 / d): one v_mul_hi_u32 instead of the ~35-instruction
+// integer division sequence (exact: the error term x * (rcp*d - 2^32) stays below 2^32).
+__device__ inline int fdiv(int x, uint32_t rcp) { return (int)__umulhi((uint32_t)x, rcp); }
+static inline uint32_t fdiv_rcp(int d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
+
 // workgroup barrier that waits for LDS traffic only (no vmcnt wait: outstanding global stores keep draining)
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <int SD, bool SPREAD, int NT>
@@ -451,6 +457,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
   const int n = c.n_agents, ng = n, no = c.n_obs, k = c.top_k;
   constexpr int ND = SD + 3;
   const int NR = n * R;
+  // index divisions by n, k, n_obs, 4*n_obs through host-precomputed reciprocals (d == 1: identity)
+#define DIVN(x) (n == 1 ? (x) : fdiv((x), a.rcp_n))
+#define DIVK(x) (k == 1 ? (x) : fdiv((x), a.rcp_k))
+#define DIVNO(x) (no == 1 ? (x) : fdiv((x), a.rcp_no))
+#define DIVNO4(x) fdiv((x), a.rcp_no4)
   // ---- LDS carve (float4-aligned blocks first) ----
   float4* s_seg = reinterpret_cast<float4*>(smem);                 // no*4: x3, y3, ex, ey
   float4* s_as = s_seg + no * 4;                                   // n*no*4: per (agent, segment) ax, ay, na
@@ -529,23 +540,23 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
     const int n_in = do_sense ? n * no : 0, n_as = do_sense ? n * no * 4 : 0;
     for (int idx = tid; idx < n_aa + n_ao + n_ga + n_in + n_as; idx += nt) {
       if (idx < n_aa) {
-        const int i = idx / n, j = idx - i * n;
+        const int i = DIVN(idx), j = idx - i * n;
         const float dx = s_agent[i * SD] - s_agent[j * SD], dy = s_agent[i * SD + 1] - s_agent[j * SD + 1];
         s_pair[idx] = sqrtf(dx * dx + dy * dy) + ((j == i) ? 1e6f : 0.0f);
       } else if (idx < n_aa + n_ao) {
-        const int q = idx - n_aa, i = q / k;
+        const int q = idx - n_aa, i = DIVK(q);
         const float dx = s_hpre[q * 2] - s_agent[i * SD], dy = s_hpre[q * 2 + 1] - s_agent[i * SD + 1];
         s_pair[idx] = sqrtf(dx * dx + dy * dy);
       } else if (idx < n_aa + n_ao + n_ga) {
         const int q = idx - n_aa - n_ao;
-        const int g = SPREAD ? q / n : q, j = SPREAD ? q - g * n : q;
+        const int g = SPREAD ? DIVN(q) : q, j = SPREAD ? q - g * n : q;
         const float dx = s_goal[g * SD] - s_agent[j * SD], dy = s_goal[g * SD + 1] - s_agent[j * SD + 1];
         s_pair[idx] = sqrtf(dx * dx + dy * dy);
       } else if (idx < n_aa + n_ao + n_ga + n_in) {
-        const int q = idx - n_aa - n_ao - n_ga, i = q / no, o = q - i * no;
+        const int q = idx - n_aa - n_ao - n_ga, i = DIVNO(q), o = q - i * no;
         s_ino[q] = rect_inside(s_obst + o * 16, s_next[i * SD], s_next[i * SD + 1], 0.0f) ? 1.0f : 0.0f;
       } else {  // ray-independent part of the segment test: (x1-x3, y1-y3, (y4-y3)(x1-x3) - (x4-x3)(y1-y3))
-        const int q = idx - n_aa - n_ao - n_ga - n_in, i = q / (no * 4), sgi = q - i * (no * 4);
+        const int q = idx - n_aa - n_ao - n_ga - n_in, i = DIVNO4(q), sgi = q - i * (no * 4);
         const float4 sg = s_seg[sgi];
         const float ax = s_next[i * SD] - sg.x, ay = s_next[i * SD + 1] - sg.y;
         s_as[q] = make_float4(ax, ay, sg.w * ax - sg.z * ay, 0.0f);
@@ -744,7 +755,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
       bool mask;
       float4 f;
       if (e < n_aa) {
-        i = e / n;
+        i = DIVN(e);
         const int j = e - i * n;
         const float* fi = s_fa + i * 4;
         const float* fj = s_fa + j * 4;
@@ -755,7 +766,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
       } else if (e < n_aa + n_ag) {
         const int e2 = e - n_aa;
         int g;
-        if (SPREAD) { i = e2 / n; g = e2 - i * n; } else { i = e2; g = e2; }
+        if (SPREAD) { i = DIVN(e2); g = e2 - i * n; } else { i = e2; g = e2; }
         const float* fi = s_fa + i * 4;
         const float* fg = s_fg + g * 4;
         f = make_float4(fi[0] - fg[0], fi[1] - fg[1], fi[2] - fg[2], fi[3] - fg[3]);
@@ -763,7 +774,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
         sender = n + g;
       } else {
         const int e3 = e - n_aa - n_ag;
-        i = e3 / k;
+        i = DIVK(e3);
         const float lx = s_next[i * SD] - s_hnext[e3 * 2], ly = s_next[i * SD + 1] - s_hnext[e3 * 2 + 1];
         f = make_float4(lx, ly, 0.0f, 0.0f);
         mask = sqrtf(lx * lx + ly * ly) < c.lidar_mask_radius;
@@ -786,6 +797,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
   }
   STAMP(9);
 }
+#undef DIVN
+#undef DIVK
+#undef DIVNO
+#undef DIVNO4
 
 static size_t lidar_smem_bytes(const dgppo_env_cfg& c) {
   const size_t n = c.n_agents, no = c.n_obs, R = 32, k = c.top_k, SD = c.state_dim, NR = n * R;
@@ -845,6 +860,8 @@ static int32_t launch_step(const dgppo_env_cfg* cfg, int mode, const float* agen
   }
   a.mode = mode;
   a.B = B;
+  a.rcp_n = fdiv_rcp(cfg->n_agents); a.rcp_k = fdiv_rcp(cfg->top_k); a.rcp_no = fdiv_rcp(cfg->n_obs);
+  a.rcp_no4 = fdiv_rcp(4 * (cfg->n_obs > 0 ? cfg->n_obs : 1));
   const size_t smem = step_smem_bytes(*cfg);
   DGPPO_REQUIRE(smem <= 64 * 1024, "env too large for the per-env LDS stage (%zu bytes)", smem);
   int work = cfg->n_agents * (lidar ? cfg->n_rays : 1);
