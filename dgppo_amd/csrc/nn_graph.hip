@@ -65,6 +65,7 @@ struct FeatArgs {
   float* efeat;   // [G*n, S, 4]
   float* emask;   // [G*n, S]
   int Fp;
+  uint32_t rcp_fp, rcp_S;   // ceil(2^32 / d): index divisions by Fp and S as one v_mul_hi_u32 (exact for idx < 2^16)
 };
 
 __device__ inline float dist_rn(float dx, float dy) { return __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy))); }
@@ -117,7 +118,7 @@ __global__ void graph_feats_kernel(FeatArgs a) {
   // node feature rows: [state | obs, goal, agent indicator], zero padded to Fp
   constexpr int ND = SD + 3;
   for (int idx = tid; idx < t.Ns * Fp; idx += nt) {
-    const int nd = idx / Fp, col = idx - nd * Fp;
+    const int nd = (int)__umulhi((uint32_t)idx, a.rcp_fp), col = idx - nd * Fp;
     float v = 0.0f;
     if (nd < n) v = (col < SD) ? s_ag[nd * SD + col] : ((col == SD + 2) ? 1.0f : 0.0f);
     else if (nd < n + ng) v = (col < SD) ? s_go[(nd - n) * SD + col] : ((col == SD + 1) ? 1.0f : 0.0f);
@@ -128,7 +129,7 @@ __global__ void graph_feats_kernel(FeatArgs a) {
   }
   // per-slot edge feature + mask
   for (int idx = tid; idx < n * S; idx += nt) {
-    const int i = idx / S, s = idx - i * S;
+    const int i = (int)__umulhi((uint32_t)idx, a.rcp_S), s = idx - i * S;
     float4 f;
     bool mask;
     const float* fi = s_fa + i * 4;
@@ -185,6 +186,9 @@ extern "C" int32_t dgppo_graph_feats(const dgppo_env_cfg* cfg, const float* agen
   a.agent = agent; a.agent_se = agent_se; a.agent_st = agent_st; a.goal = goal; a.obst = obst;
   a.hits = hits; a.hits_se = hits_se; a.hits_st = hits_st; a.env_ids = env_ids; a.n_env = n_env; a.n_time = n_time;
   a.Xa = Xa; a.Xo = Xo; a.efeat = efeat; a.emask = emask; a.Fp = Fp;
+  a.rcp_fp = (uint32_t)((0x100000000ull + (uint64_t)Fp - 1) / (uint64_t)Fp);
+  a.rcp_S = (uint32_t)((0x100000000ull + (uint64_t)a.t.S - 1) / (uint64_t)a.t.S);
+  DGPPO_REQUIRE(Fp >= 2 && a.t.S >= 2 && (long)a.t.Ns * Fp < 65536 && (long)a.t.n * a.t.S < 65536, "graph_feats: sizes out of range");
   const int SD = cfg->state_dim;
   const size_t smem = sizeof(float) * ((size_t)a.t.n * SD + a.t.ng * SD + (size_t)n_on * SD + a.t.n * 4 + a.t.ng * 4);
   const long G = (long)n_env * n_time;
