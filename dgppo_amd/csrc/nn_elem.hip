@@ -223,8 +223,11 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
         int s = s0 + rt * 16 + lq * 4 + r;
         ok[rt][r] = s < a.n_seq;
         s = ok[rt][r] ? s : a.n_seq - 1;
-        const int grp = s / a.n_inner;
-        row0[rt][r] = grp * a.T * a.n_inner + (s - grp * a.n_inner);
+        // row(s, tau = 0); with T == 1 (or one sequence per group) rows and sequences coincide: no integer division
+        int rw = s;
+        if (a.T != 1 && a.n_inner != 1) { const int grp = s / a.n_inner; rw = grp * a.T * a.n_inner + (s - grp * a.n_inner); }
+        else if (a.T != 1) rw = s * a.T;
+        row0[rt][r] = rw;
       }
     for (int tau = 0; tau < a.T; ++tau) {
       const float* hs_cur = sm + cur * (RB * GRU_HL);
@@ -314,8 +317,11 @@ __global__ void __launch_bounds__(256) gru_bwd_kernel(GruArgs a) {
         int s = s0 + rt * 16 + lq * 4 + r;
         ok[rt][r] = s < a.n_seq;
         s = ok[rt][r] ? s : a.n_seq - 1;
-        const int grp = s / a.n_inner;
-        row0[rt][r] = grp * a.T * a.n_inner + (s - grp * a.n_inner);
+        // row(s, tau = 0); with T == 1 (or one sequence per group) rows and sequences coincide: no integer division
+        int rw = s;
+        if (a.T != 1 && a.n_inner != 1) { const int grp = s / a.n_inner; rw = grp * a.T * a.n_inner + (s - grp * a.n_inner); }
+        else if (a.T != 1) rw = s * a.T;
+        row0[rt][r] = rw;
       }
     float rg[RTW][4], zg[RTW][4], ng[RTW][4], hn[RTW][4], hp[RTW][4], du[RTW][4], dh[RTW][4];
     auto fetch = [&](int tau) {
