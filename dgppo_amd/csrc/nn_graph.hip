@@ -656,7 +656,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   static_assert(CT * FQ <= ATW_BX && KZ * FT <= ATW_BZ && RT <= ATW_RT, "fragments exceed the register budget");
   const Topo& t = a.t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-  const int g = blockIdx.x * 4 + wave;
+  // wave-uniform by construction; readfirstlane tells the compiler, so the per-graph base pointers live in SGPRs and the
+  // loads use scalar-base + 32-bit-offset addressing instead of 64-bit vector address arithmetic
+  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   if (g >= a.G) return;                                        // no barriers below: a wave may leave on its own
   const int n = t.n, S = t.S, Ns = t.Ns, H = a.H, nH = n * H, Kp = a.Kp;
   const int Wd = F + 4, kc = F + H * Wd;
@@ -874,7 +876,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   constexpr int FQ = F / 4, FT = (F + 15) / 16, KZ = CT * 4, Ll = CT * 16 + 1, RT = (NP + 1) / 2, KP = RT * 4;
   const Topo& t = a.t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-  const int g = blockIdx.x * 4 + wave;
+  // wave-uniform by construction; readfirstlane tells the compiler, so the per-graph base pointers live in SGPRs and the
+  // loads use scalar-base + 32-bit-offset addressing instead of 64-bit vector address arithmetic
+  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
   if (g >= a.G) return;
   const int n = t.n, S = t.S, Ns = t.Ns, H = a.H, nH = n * H, Kp = a.Kp;
   const int Wd = F + 4;
