@@ -62,6 +62,44 @@ def test_dense_bwd_w(cuda, M, K, N):
     _close(db, dY.double().sum(0), 3e-6 * math.sqrt(M), "db")
 
 
+def test_dense_kernels_random_shape_sweep(cuda):
+    """seeded sweep over the instantiation space of the persistent dense kernels: K in [1, 256] (every padded-K variant,
+    K % 4 != 0 takes the scalar staging path), N in [1, 192], ragged M incl. M < one tile, strided X / Y views, transposed
+    W, accumulate, relu; and the two-stage weight gradient with and without bias."""
+    from dgppo_amd import ops_nn as K_
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(7)
+    Ks = [1, 3, 4, 7, 8, 15, 16, 17, 32, 33, 48, 63, 64, 65, 96, 100, 128, 144, 160, 192, 255, 256]
+    for trial in range(36):
+        Kd = int(rng.choice(Ks)); Nd = int(rng.integers(1, 193)); M = int(rng.choice([1, 5, 31, 32, 33, 64, 257, 1000, 4099]))
+        trans, acc, act = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(0, 2))
+        strided = bool(rng.integers(0, 2)) and Kd % 4 == 0
+        Xf = torch.randn(M, Kd + (8 if strided else 0), generator=g)
+        X = Xf[:, 4:4 + Kd] if strided else Xf
+        W = torch.randn(Nd, Kd, generator=g) if trans else torch.randn(Kd, Nd, generator=g)
+        b = torch.randn(Nd, generator=g) if rng.integers(0, 2) else None
+        Y0 = torch.randn(M, Nd, generator=g)
+        want = X @ (W.T if trans else W) + (b if b is not None else 0.0)
+        if acc:
+            want = want + Y0
+        if act:
+            want = torch.relu(want)
+        Xd = Xf.to(cuda)[:, 4:4 + Kd] if strided else X.to(cuda)
+        Y = Y0.to(cuda).clone() if acc else torch.full((M, Nd), float("nan"), device=cuda)
+        K_.dense_fwd(Xd, W.to(cuda), None if b is None else b.to(cuda), Y, act=act, accumulate=acc, trans_w=trans)
+        _close(Y, want, 3e-6 * math.sqrt(Kd) + 1e-6, f"dense_fwd M={M} K={Kd} N={Nd} trans={trans} acc={acc} act={act} strided={strided}")
+    for trial in range(20):
+        Kd = int(rng.choice(Ks)); Nd = int(rng.integers(1, 193)); M = int(rng.choice([1, 31, 64, 65, 300, 2049, 9000]))
+        X = torch.randn(M, Kd, generator=g); dY = torch.randn(M, Nd, generator=g)
+        dW0 = torch.randn(Kd, Nd, generator=g); db0 = torch.randn(Nd, generator=g)
+        use_b = bool(rng.integers(0, 2))
+        dW = dW0.to(cuda).clone(); db = db0.to(cuda).clone() if use_b else None
+        K_.dense_bwd_w(X.to(cuda), dY.to(cuda), dW, db)
+        _close(dW, dW0 + X.T @ dY, 3e-6 * math.sqrt(M) + 1e-6, f"dense_bwd_w M={M} K={Kd} N={Nd}")
+        if use_b:
+            _close(db, db0 + dY.sum(0), 3e-6 * math.sqrt(M) + 1e-6, f"dense_bwd_w bias M={M} N={Nd}")
+
+
 @pytest.mark.parametrize("M,save,strided", [(1, True, False), (33, False, False), (1000, True, True), (40000, True, False)])
 def test_mlp_gi_fused(cuda, M, save, strided):
     """fused Dense->LN->ReLU->Dense->LN->ReLU->Dense(192) against the plain torch fp32 composition (mlp.py:17-29,
