@@ -547,3 +547,48 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
     for name in ("block", "valu"):
         for k in ref:
             _close(outs[name][k], ref[k], 2e-5, f"{name}.{k}")
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [(0, 2, 1), (0, 3, 0), (0, 5, 2), (0, 10, 3), (1, 6, 2), (3, 4, 3), (4, 6, 5), (2, 4, 2),
+                                           (0, 8, 5), (1, 10, 1)])
+def test_attention_wave_kernels_across_topologies(cuda, monkeypatch, kind, n, n_obs):
+    """the one-wave-per-graph kernels are compiled per (node tiles CT, softmax passes NP, slots per lane SJ): walk
+    different environment topologies (fan-in 2..35, 3..71 nodes) and compare forward and backward with the VALU
+    kernels, whose code does not depend on those parameters (shapes without a wave instantiation take a fallback on both
+    sides, which then simply must agree with itself)."""
+    from dgppo_amd import _native as N, ops_nn as K_
+    cfg = N.make_env_cfg(kind, n, n_obs)
+    S, H = cfg.fan_in, 3
+    n_other = cfg.num_nodes - 1 - n
+    G = 21
+    gen = torch.Generator().manual_seed(kind * 100 + n * 10 + n_obs)
+    R = G * n
+    for F, Kp in ((8, 48), (32, 144)):
+        qt = torch.randn(R, H * F, generator=gen).to(cuda)
+        Xa = torch.randn(R, F, generator=gen).to(cuda)
+        Xo = torch.randn(max(G * n_other, 1), F, generator=gen).to(cuda)[:G * n_other]
+        em = (torch.rand(R, S, generator=gen) > 0.3).float()
+        em[:, 0] = 1.0
+        ef = torch.randn(R, S, 4, generator=gen)
+        ef[em == 0] = float("nan")
+        em, ef = em.to(cuda), ef.to(cuda)
+        dz = torch.randn(R, Kp, generator=gen).to(cuda)
+
+        def run():
+            z = torch.full((R, Kp), float("nan"), device=cuda)
+            at = torch.full((R, S, H), float("nan"), device=cuda)
+            K_.attn_fwd(cfg, F, H, Kp, qt, Xa, Xo if n_other > 0 else None, ef, em, z, at, G)
+            dq = torch.full((R, H * F), float("nan"), device=cuda)
+            dXa = torch.full((R, F), float("nan"), device=cuda)
+            dXo = torch.full((G * n_other, F), float("nan"), device=cuda) if n_other > 0 else None
+            K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo if n_other > 0 else None, ef, dq, dXa, dXo, G)
+            torch.cuda.synchronize()
+            return dict(z=z, at=at, dq=dq, dXa=dXa, **({"dXo": dXo} if dXo is not None else {}))
+
+        got = run()
+        monkeypatch.setenv("DGPPO_ATTN_VALU", "1")
+        ref = run()
+        monkeypatch.delenv("DGPPO_ATTN_VALU")
+        for k in ref:
+            assert torch.isfinite(got[k]).all(), f"{k} not finite (F={F})"
+            _close(got[k], ref[k], 2e-5, f"F={F} {k}")
