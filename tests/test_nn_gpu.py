@@ -207,7 +207,10 @@ def test_ln_relu(cuda):
     _close(db, p["bias"].grad, 2e-5, "ln dbeta")
 
 
-@pytest.mark.parametrize("n_grp,T_,n_inner,use_h0", [(5, 16, 8, False), (70, 1, 3, True), (9, 7, 1, True), (130, 3, 1, False)])
+@pytest.mark.parametrize("n_grp,T_,n_inner,use_h0", [(5, 16, 8, False), (70, 1, 3, True), (9, 7, 1, True), (130, 3, 1, False),
+                                                     (1, 129, 1, False),       # one sequence, the pre-pass length
+                                                     (2051, 2, 8, True),       # 16 408 sequences: the 32-sequence-tile kernels
+                                                     (16390, 1, 1, True)])     # same kernels, T = 1, ragged last tile
 def test_gru_scan(cuda, n_grp, T_, n_inner, use_h0):
     from dgppo_amd import ops_nn as K_
     g = torch.Generator().manual_seed(n_grp + T_)
