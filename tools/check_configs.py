@@ -3,8 +3,11 @@ sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/dgppo_amd") else o
 import numpy as np, torch
 from dgppo_amd import _native as N, engine as EN, init
 dev = torch.device("cuda:0")
-for kind, n, obs in (("LidarBicycleTarget", 16, 8), ("MPESpread", 3, 3), ("LidarTarget", 5, 4)):
-    cfg = N.make_env_cfg(N.ENV_KINDS[kind], n, obs)
+for kind, n, obs, kw in (("LidarBicycleTarget", 16, 8, {}), ("MPESpread", 3, 3, {}), ("LidarTarget", 5, 4, {}),
+                         ("LidarSpread", 4, 2, {"n_rays": 16}),                 # generic env kernel (n_rays != 32)
+                         ("LidarSpread", 6, 3, {"comm_radius": 15.0}),          # --full-observation: comm_radius = 10 * area
+                         ("MPETarget", 1, 0, {})):                              # a single agent, no obstacles
+    cfg = N.make_env_cfg(N.ENV_KINDS[kind], n, obs, **kw)
     hp = EN.Hyper(batch_size=64 * 16, rnn_step=8, train_steps=10)
     eng = EN.Engine(cfg, hp, dev, T=16, use_graphs=True, multi_stream=True)
     eng.policy.load_tree(init.init_policy(0, cfg.node_dim, 2, hp.actor_gnn_layers))
@@ -19,4 +22,4 @@ for kind, n, obs in (("LidarBicycleTarget", 16, 8), ("MPESpread", 3, 3), ("Lidar
         info = eng.update(ro, det, it, np.random.default_rng(it).permutation(B))
     torch.cuda.synchronize()
     ok = all(np.isfinite(v) for v in info.values())
-    print(kind, n, obs, "nodes", cfg.num_nodes, "ok" if ok else "NON-FINITE", {k: round(v, 4) for k, v in list(info.items())[:4]}, f"{time.time()-t0:.1f}s")
+    print(kind, n, obs, kw, "nodes", cfg.num_nodes, "ok" if ok else "NON-FINITE", {k: round(v, 4) for k, v in list(info.items())[:4]}, f"{time.time()-t0:.1f}s")
