@@ -6,7 +6,6 @@ reproducible); `params` are flax-named trees of numpy arrays snapsh
 from __future__ import annotations
 
 import os
-import pickle
 from typing import Optional
 
 import numpy as np
@@ -17,6 +16,7 @@ from .. import init as INIT
 from .. import nets
 from .. import ops_nn as K
 from ..trainer.data import Rollout
+from ..utils import checkpoint as CK
 from ..utils.graph import GraphsTuple
 from .base import Algorithm
 
@@ -213,10 +213,10 @@ class DGPPO(Algorithm):
         p = self.params
         for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl"), ("Vh.pkl", "Vh")):
             with open(os.path.join(model_dir, fname), "wb") as f:
-                pickle.dump(p[key], f)
+                CK.save_tree(p[key], f)
 
     def load(self, load_dir: str, step: int):
         path = os.path.join(load_dir, str(step))
         for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl"), ("Vh.pkl", "Vh")):
-            with open(os.path.join(path, fname), "rb") as f:   # files written by save() above (our own pickles)
-                self.engine.nets[key].load_tree(pickle.load(f))
+            with open(os.path.join(path, fname), "rb") as f:   # weights-only unpickler: nothing in the file is executed
+                self.engine.nets[key].load_tree(CK.load_tree(f))

@@ -5,7 +5,6 @@ ones DGPPO inherits (informarl.py:357-457).  SURVEY §8f rank 3."""
 from __future__ import annotations
 
 import os
-import pickle
 
 import numpy as np
 import torch
@@ -13,6 +12,7 @@ import torch
 from .. import engine as EN
 from .. import init as INIT
 from .. import nets
+from ..utils import checkpoint as CK
 from .base import Algorithm
 from .dgppo import DGPPO
 
@@ -80,13 +80,13 @@ class InforMARL(DGPPO):
         p = self.params
         for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl")):
             with open(os.path.join(model_dir, fname), "wb") as f:
-                pickle.dump(p[key], f)
+                CK.save_tree(p[key], f)
 
     def load(self, load_dir: str, step: int):
         path = os.path.join(load_dir, str(step))
         for fname, key in (("actor.pkl", "policy"), ("Vl.pkl", "Vl")):
-            with open(os.path.join(path, fname), "rb") as f:   # files written by save() above (our own pickles)
-                self.engine.nets[key].load_tree(pickle.load(f))
+            with open(os.path.join(path, fname), "rb") as f:   # weights-only unpickler: nothing in the file is executed
+                self.engine.nets[key].load_tree(CK.load_tree(f))
 
 
 class HCBFCRPO(InforMARL):

@@ -239,3 +239,43 @@ def test_collect_then_evaluate_then_update_is_safe(cuda):
     assert algo._pending_det is None
     info = algo.update(ro, 0)
     assert all(np.isfinite(v) for v in info.values())
+
+
+@pytest.mark.parametrize("env_id,n,obs", [("LidarSpread", 3, 2), ("MPESpread", 3, 3)])
+def test_reference_signature_rollout_functions(cuda, env_id, n, obs):
+    """dgppo.trainer.utils.rollout / test_rollout with the reference's (env, actor, init_rnn_state, key) signatures
+    (dgppo/trainer/utils.py:22,60): one environment stepped through env.reset / env.step and the algo's single-graph
+    act / step.  The deterministic one must reproduce the batched engine rollout of the same scene exactly, including
+    the post-step carry convention; the stochastic one must store the pre-step carry and consistent log-probabilities."""
+    import functools as ft
+    from dgppo.env import make_env
+    from dgppo.trainer import utils as TU
+    from dgppo.trainer.data import Rollout
+    T_ = 6
+    env = make_env(env_id, n, max_step=T_, num_obs=obs)
+    algo = _mk_algo(env, batch_size=4 * T_)
+    key = 4242
+    r = TU.test_rollout(env, ft.partial(algo.act, params=None), algo.init_rnn_state, key)
+    assert isinstance(r, Rollout) and r.log_pis is None
+    assert r.actions.shape == (T_, n, 2) and r.rewards.shape == (T_,) and r.costs.shape == (T_, n, 2)
+    assert r.rnn_states.shape == (T_, 1, n, 1, 64) and r.graph.nodes.shape[0] == T_ and r.dones.shape == (T_,)
+    np.testing.assert_array_equal(_np(r.graph.nodes[1:]), _np(r.next_graph.nodes[:-1]))
+    key_x0 = TU._split(key, 2)[0]
+    b = algo.collect_deterministic(np.array([key_x0], dtype=np.int64))
+    # same kernels at B = 1; a tolerance (not bit equality) because launch geometry may differ between the two paths
+    tol = dict(atol=5e-6, rtol=0)
+    np.testing.assert_allclose(_np(r.actions), _np(b.actions[0]), **tol)
+    np.testing.assert_allclose(_np(r.rewards), _np(b.rewards[0]), **tol)
+    np.testing.assert_allclose(_np(r.costs), _np(b.costs[0]), **tol)
+    np.testing.assert_allclose(_np(r.rnn_states), _np(b.rnn_states[0]), **tol)          # post-step carry (utils.py:71-77)
+    np.testing.assert_allclose(_np(r.graph.states[:, :2 * n]), _np(b.graph.states[0][:, :2 * n]), **tol)
+    # stochastic: pre-step carry stored (utils.py:46-51) — rnn_states[0] is the initial carry, rnn_states[t+1] is what the
+    # actor returned at step t; log_pi is the actor's own
+    s = TU.rollout(env, ft.partial(algo.step, params=None), algo.init_rnn_state, key)
+    assert s.log_pis.shape == (T_, n) and s.rnn_states.shape == (T_, 1, n, 1, 64)
+    assert float(s.rnn_states[0].abs().max()) == 0.0
+    k_x0, _, k_steps = TU._split(key, 3)
+    _, lp1, h1 = algo.step(env.reset(k_x0), algo.init_rnn_state, TU._split(k_steps, T_)[0])
+    np.testing.assert_array_equal(_np(s.log_pis[0]), _np(lp1))
+    np.testing.assert_array_equal(_np(s.rnn_states[1]), _np(h1))
+    assert float(s.actions.abs().max()) <= 1.0 and bool(torch.isfinite(s.log_pis).all())
