@@ -7,7 +7,9 @@ all PPO minibatch updates (Vl, Vh, policy; clip + Adam), i.e. exactly what `algo
 iteration (dgppo/trainer/trainer.py:131-137).  Counted work = B*T env-steps of the stochastic rollout per iteration
 (BASELINE.md §3).  Synthetic random scenes, random-init networks.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N>1: one rank per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ...` the ranks come from the
+        environment; a bare `python bench.py --gpus N` starts the N ranks itself (before touching the GPU).
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (raycast+graph kernel vs the HBM roofline, timed with HIP events
 inside this process), "cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample), "phases".
@@ -24,7 +26,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# peaks this file prices against (MI355X_MICROARCH.md "Chip-level parameters"); printed in the JSON line as "peaks"
+HBM_PEAK_GBS = 8000.0          # HBM3E spec; ~6300 GB/s is the measured float4-copy ceiling on this part
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector = fp32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
 
 
 def log(msg):
@@ -99,53 +103,110 @@ def roofline_env_kernel(cfg, device, B, iters=50):
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seconds_budget: float):
-    """CPU restatement (JAX not installable offline): the oracle's full DGPPO iteration on a bounded sample."""
+    """CPU restatement (JAX not installable offline): the oracle's full DGPPO iteration on a bounded sample of
+    the workload — B = 256 envs with a 16-step horizon so that one iteration is ~30 s of CPU work: same
+    topology (LidarSpread n=8 obs=3), same 128 envs per minibatch, rnn_step 16, two minibatches; every env-step costs
+    what it costs at T = 128 except the O(T^2) GAE, which is negligible here.  Measured twice: all host threads and one
+    thread.  No extrapolation: value = counted env-steps / wall time."""
     from oracle import train_ref
-    torch.set_num_threads(host_threads())
-    B, T = 8, 128
-    t0 = time.time()
-    r = train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=B * T // 2, seed=0)
-    dt = time.time() - t0
-    log(f"cpu_baseline: first oracle iteration took {dt:.1f} s on {torch.get_num_threads()} threads")
-    iters = 1
-    while dt < seconds_budget * 0.75 and iters < 12:
-        t1 = time.time()
-        train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=B * T // 2, seed=iters)
-        dt += time.time() - t1
-        iters += 1
-    return {"value": B * T * iters / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} full DGPPO iteration(s) of the CPU oracle (numpy env + torch-CPU per-edge networks + autograd), "
-                      f"LidarSpread n=8 obs=3, {B} envs x {T} steps, batch {B * T // 2}; {dt:.1f} s"}
+    B, T = 256, 16
+    bs = 128 * T
+    out = {}
+    for label, thr in (("all", host_threads()), ("one", 1)):
+        torch.set_num_threads(thr)
+        t0 = time.time()
+        train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=bs, seed=0)
+        dt = time.time() - t0
+        log(f"cpu_baseline[{label}]: one oracle iteration (B={B}, T={T}) took {dt:.1f} s on {thr} thread(s)")
+        out[label] = (B * T / dt, thr, dt)
+        if label == "all" and dt > 3.0 * seconds_budget:
+            log("cpu_baseline: skipping the 1-thread run (the all-thread run already exceeded 3x the budget)")
+            break
+    v, thr, dt = out["all"]
+    res = {"value": v, "unit": "env-steps/s", "cores": thr, "kind": "port", "cpu_model": cpu_model(),
+           "host_cpus_visible": os.cpu_count(),
+           "sample": f"1 full DGPPO iteration of the CPU oracle (numpy-fp32 env + torch-CPU per-edge networks + autograd), "
+                     f"LidarSpread n=8 obs=3, {B} envs x {T} steps, batch {bs} (128 envs/minibatch), rnn_step 16; {dt:.1f} s; "
+                     f"CPU restatement (JAX not installable offline)"}
+    if "one" in out:
+        res["one_thread"] = {"value": out["one"][0], "cores": 1, "seconds": out["one"][2]}
+    return res
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` with no torchrun environment: the parent starts the N ranks itself — BEFORE it makes any GPU
+    call (it never initialises HIP) — relays rank 0's JSON line and fails if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                  # nothing above touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    n_dev = torch.cuda.device_count()                # counting devices does not initialise HIP
+    backend = os.environ.get("DGPPO_DIST_BACKEND", "rccl")
+    if world > n_dev and backend != "gloo":
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s) visible.  RCCL needs one device per rank; "
+                         f"DGPPO_DIST_BACKEND=gloo rehearses several ranks on one GPU.")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    n_dev = torch.cuda.device_count()
-    dev_index = local_rank % max(n_dev, 1)       # ranks > devices only in rehearsals (several ranks sharing one GPU, gloo)
+    dev_index = local_rank % max(n_dev, 1)           # ranks > devices only in gloo rehearsals
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    from dgppo_amd import _native as N, engine as EN, init, dist as D
-    D.init(backend=os.environ.get("DGPPO_DIST_BACKEND", "nccl"), device=device)   # (gloo: rehearsal of N ranks on one GPU)
-    allreduce = D.make_allreduce(world)          # RCCL all-reduce of each net's flat gradient buffer per minibatch step
-    if allreduce is not None:                    # build the communicator outside any timed region
+    from dgppo_amd import _native as N, engine as EN, init, dist as D, ops_nn as K
+    D.init_control_plane()
+    # data plane: ONE dgppo_comm_allreduce_sum_f32 (RCCL, C ABI) of the flat gradient buffer per minibatch step
+    allreduce, close_comm = D.make_allreduce(world, backend)
+    if allreduce is not None:                        # first collective (connection setup) outside any timed region
         allreduce(torch.zeros(1 << 16, device=device))
         torch.cuda.synchronize()
 
     cfg = N.make_env_cfg(N.ENV_KINDS[args.env], args.num_agents, args.obs)
     T = 128
     hp = EN.Hyper(batch_size=args.batch_size, train_steps=1000)
-    eng = EN.Engine(cfg, hp, device, T=T, allreduce=allreduce, use_graphs=True, multi_stream=True)
+    eng = EN.Engine(cfg, hp, device, T=T, allreduce=allreduce, world=world, use_graphs=True, multi_stream=True)
     eng.policy.load_tree(init.init_policy(0, cfg.node_dim, 2, hp.actor_gnn_layers))
     eng.Vl.load_tree(init.init_value(0, cfg.node_dim, 1, hp.Vl_gnn_layers, 2))
     eng.Vh.load_tree(init.init_value(0, cfg.node_dim, 2, hp.Vh_gnn_layers, 3))
     eng.set_entropy_noise(12345)
     B = args.n_env
-    rng = np.random.default_rng(1000 + rank)
+    rng = np.random.default_rng(1000)                # the same permutation on every rank (shared seed, SURVEY §8e)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phases = {"collect+det_rollout": 0.0, "update": 0.0}
 
@@ -166,29 +227,33 @@ def main():
             phases["update"] += e[1].elapsed_time(e[2])
         return info
 
-    log(f"rank {rank}/{world}: engine ready, B={B} envs, starting {args.warmup} warm-up iteration(s)")
+    log(f"rank {rank}/{world}: engine ready on {torch.cuda.get_device_name(device)} (backend {backend}), B={B} envs, "
+        f"starting {args.warmup} warm-up iteration(s)")
     for w in range(args.warmup):
         iteration(w, False)
         torch.cuda.synchronize()
         log(f"warm-up {w} done")
     torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
+    D.barrier(world)
     torch.cuda.synchronize()
+    flops0 = K.FLOPS[0]
     t0 = time.perf_counter()
     info = None
+    step_ms = []
     for k in range(args.steps):
-        info = iteration(args.warmup + k, True)
+        tk = time.perf_counter()
+        info = iteration(args.warmup + k, True)      # ends with the host sync of the logged scalars
+        step_ms.append((time.perf_counter() - tk) * 1e3)
         log(f"timed iteration {k} done ({time.perf_counter() - t0:.2f} s since start)")
     torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
+    D.barrier(world)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, world, device)
+    flops_per_step = (K.FLOPS[0] - flops0) / args.steps
+    dt = D.max_over_ranks(dt, world)
     if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
+        close_comm()
+        D.shutdown(world)
         return
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * T * args.steps / dt
@@ -201,9 +266,11 @@ def main():
     for r in range(3):
         eng.rollout(seeds, True, noise_seed=2 + r)
     torch.cuda.synchronize()
-    rollout_only = world * B * T * 3 / (time.perf_counter() - t1)
+    rollout_only = B * T * 3 / (time.perf_counter() - t1)
     rl = roofline_env_kernel(cfg, device, B) if cfg.is_lidar and cfg.n_obs > 0 else None
+    rl_big = roofline_env_kernel(cfg, device, 4 * B, iters=30) if rl is not None else None
     log(f"roofline kernel: {rl}")
+    sm = np.sort(np.asarray(step_ms))
     out = {
         "metric": "env-steps/sec whole node, LidarSpread n=8 4096 envs, 1/2/4/8 GPUs",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,32 +278,49 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.env} n={args.num_agents} obs={args.obs}, {B} envs/GPU x T=128, full DGPPO iteration "
                                f"(collect + det rollout + value pre-passes + GAE + {B // (args.batch_size // T)} minibatches "
-                               f"of batch_size {args.batch_size}, rnn_step 16)",
-                   "envs_per_gpu": B, "global_envs": world * B, "parallelism": f"dp{world}"},
+                               f"of batch_size {args.batch_size} per GPU, rnn_step 16)",
+                   "envs_per_gpu": B, "global_envs": world * B, "parallelism": f"dp{world}",
+                   "collective": None if world == 1 else f"{backend}: 1 all-reduce(sum) of {eng.n_reduced} fp32 per minibatch"},
+        "ms_per_step_stats": {"median": float(np.median(sm)), "min": float(sm[0]), "max": float(sm[-1]), "n": len(sm),
+                              "note": "rank-0 wall time per iteration (each ends with the host sync of the logged scalars)"},
         "phases_ms_per_step": {k: v / args.steps for k, v in phases.items()},
-        "rollout_only_env_steps_per_s": rollout_only,
+        "rollout_only_env_steps_per_s_per_gpu": rollout_only,
+        "mfma": {"flops_executed_per_step": flops_per_step, "unit": "flop (fp32, 2 per multiply-add, unpadded operand shapes)",
+                 "tflops": flops_per_step / (ms_per_step * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
+                 "util": flops_per_step / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                 "note": "matrix-core work of one rank's iteration / its wall time (includes rollouts, GAE and all non-MFMA time)"},
+        "peaks": {"hbm_GBps": HBM_PEAK_GBS, "fp32_TFLOPs": FP32_PEAK_TFLOPS, "source": "MI355X_MICROARCH.md (spec values)",
+                  "device": torch.cuda.get_device_name(device)},
         "last_info": {k: info[k] for k in ("policy/loss", "Vl/loss", "Vh/loss_Vh", "eval/safe_data")},
     }
     if rl is not None:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_env_step_traffic.json")
-        if os.path.exists(tpath) and B == 4096 and args.env == "LidarSpread" and args.num_agents == 8 and args.obs == 3:
-            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE), see profiles/README.md
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch_api_fetch_x2"]
-        out["roofline"] = {"bound": "hbm", "kernel": "env_step_kernel (dynamics + raycast + top-k + reward/cost + GraphsTuple emit)",
+        traffic, tsrc = None, None
+        for name in ("r02_env_step_traffic.json", "r01_env_step_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tpath) and B == 4096 and args.env == "LidarSpread" and args.num_agents == 8 and args.obs == 3:
+                # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE), see profiles/README.md
+                traffic, tsrc = json.load(open(tpath))["hbm_bytes_per_launch_api_fetch_x2"], f"profiles/{name} (rocprofv3 --pmc, offline)"
+                break
+        comp = dict(rl["compact"])
+        flop_ray = 30.0 * cfg.n_agents * cfg.n_rays * cfg.n_obs * 4          # SURVEY §8d F_ray
+        comp["valu_tflops"] = flop_ray * comp["env_steps_per_s"] / 1e12
+        comp["valu_frac_of_fp32_peak"] = comp["valu_tflops"] / FP32_PEAK_TFLOPS
+        out["roofline"] = {"bound": "hbm", "kernel": "lidar_wave_kernel (dynamics + raycast + top-k + reward/cost + GraphsTuple emit)",
                            "achieved": rl["api"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rl["api"]["gbs"] / HBM_PEAK_GBS,
-                           "traffic": traffic, "traffic_source": "profiles/r01_env_step_traffic.json (rocprofv3 --pmc, offline)",
+                           "traffic": traffic, "traffic_source": tsrc,
                            "algorithmic_bytes_per_launch": rl["api"]["bytes_per_env_step"] * B, "bytes_per_env_step": rl["api"]["bytes_per_env_step"],
                            "us_per_launch": rl["api"]["us_per_launch"], "kernel_env_steps_per_s": rl["api"]["env_steps_per_s"],
-                           "compact": rl["compact"]}
+                           "at_4x_envs": {"envs": 4 * B, "us_per_launch": rl_big["api"]["us_per_launch"], "achieved": rl_big["api"]["gbs"],
+                                          "frac": rl_big["api"]["gbs"] / HBM_PEAK_GBS},
+                           "compact": comp}
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         except Exception as ex:  # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"error": repr(ex)}
-    print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    close_comm()
+    D.shutdown(world)
 
 
 if __name__ == "__main__":

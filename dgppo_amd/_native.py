@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdgppo_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ENV_KINDS = {"LidarSpread": 0, "LidarTarget": 1, "LidarBicycleTarget": 2, "MPESpread": 3, "MPETarget": 4}
 RECT_STRIDE = 16

@@ -65,7 +65,7 @@ class DGPPO(Algorithm):
                  epoch_ppo: int = 1, clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2,
                  max_grad_norm: float = 2.0, seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16,
                  use_lstm: bool = False, alpha: float = 10.0, cbf_eps: float = 1e-2, cbf_weight: float = 1.0,
-                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, **kwargs):
+                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, world: int = 1, **kwargs):
         super().__init__(env, node_dim, edge_dim, action_dim, n_agents)
         if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
             raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1 "
@@ -80,7 +80,7 @@ class DGPPO(Algorithm):
                            train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers, Vl_gnn_layers=Vl_gnn_layers,
                            Vh_gnn_layers=Vh_gnn_layers)
         self.device = env.device
-        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce,
+        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
                                 use_graphs=True, multi_stream=True)
         self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
         self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))

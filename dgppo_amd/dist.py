@@ -1,42 +1,90 @@
-"""Data-parallel plumbing: one process per GPU, `torch.distributed` over RCCL (backend "nccl" on ROCm; "gloo" in the CPU
-tests).  The hot path shards naturally: every rank owns its own envs, rollouts, value pre-passes, GAE and
-advantages with NO communication; the only exchange is one all-reduce(sum) of each network's flat fp32 gradient buffer per
-minibatch step, after which every rank applies the identical clip + Adam update (replicas stay bit-identical)."""
+"""Data-parallel plumbing: one process per GPU.  The hot path shards naturally: every rank owns its own envs,
+rollouts, value pre-passes, GAE and advantages with NO communication; the only exchange is ONE all-reduce(sum) per
+minibatch of the engine's flat `[g_policy | g_Vl | g_Vh | loss sums]` fp32 buffer, after which every rank applies the
+identical NaN-check -> norm -> clip -> Adam with `grad_scale = 1/world` (replicas stay bit-identical).
+
+Two planes:
+  * data plane   — `RcclComm`: the C-ABI entry points `dgppo_comm_{unique_id,init,allreduce_sum_f32,destroy}` of
+                   libdgppo_hip.so (RCCL over xGMI, enqueued on the caller's HIP stream; include/dgppo_hip.h §C1);
+  * control plane — a `torch.distributed` gloo group on the host: ships the 128-byte rendezvous id, barriers, and the
+                   max-over-ranks of the benchmark clock.  (backend "gloo" also serves as a data plane for rehearsals of
+                   several ranks on ONE GPU, where RCCL refuses duplicate devices, and for the CPU tests.)
+"""
 from __future__ import annotations
 
+import ctypes as C
+import datetime
 import os
 from typing import Callable, Optional
 
 import numpy as np
 import torch
 
+ID_BYTES = 128
+
 
 def env_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend: Optional[str] = None, device: Optional[torch.device] = None):
-    """idempotent init from the torchrun environment; returns (rank, world)."""
+def init_control_plane(timeout_s: int = 600):
+    """idempotent gloo group from the torchrun-style environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT);
+    returns (rank, world)."""
     import torch.distributed as dist
-    rank, local_rank, world = env_info()
+    rank, _, world = env_info()
     if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-        dist.init_process_group(backend, **kw)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
     return rank, world
 
 
-def make_allreduce(world: int) -> Optional[Callable[[torch.Tensor], None]]:
-    """gradient hook for Engine: sum over ranks, then scale by 1/world (losses are means over equal-sized shards, so the
-    mean of the shard gradients is the gradient of the global mean)."""
+class RcclComm:
+    """RCCL communicator behind the C ABI.  Construct on every rank AFTER `torch.cuda.set_device` (the communicator binds
+    to the current HIP device) and after `init_control_plane()`."""
+
+    def __init__(self, rank: int, world: int):
+        import torch.distributed as dist
+        from . import _native as N
+        self._N, self.rank, self.world = N, rank, world
+        lib = N.lib()
+        buf = (C.c_uint8 * ID_BYTES)()
+        if rank == 0:
+            N.check(lib.dgppo_comm_unique_id(buf), "dgppo_comm_unique_id")
+        idt = torch.tensor(list(buf), dtype=torch.uint8)
+        dist.broadcast(idt, src=0)                                   # host tensor over the gloo control plane
+        for i, b in enumerate(idt.tolist()):
+            buf[i] = b
+        self._handle = C.c_void_p()
+        N.check(lib.dgppo_comm_init(buf, C.c_int32(rank), C.c_int32(world), C.byref(self._handle)), "dgppo_comm_init")
+
+    def allreduce_sum(self, flat: torch.Tensor) -> None:
+        """in-place sum over the ranks, enqueued on torch's current stream"""
+        N = self._N
+        rc = N.lib().dgppo_comm_allreduce_sum_f32(self._handle, N.ptr(flat), C.c_int64(flat.numel()), N.stream_ptr())
+        N.check(rc, "dgppo_comm_allreduce_sum_f32")
+
+    def destroy(self) -> None:
+        if self._handle:
+            self._N.check(self._N.lib().dgppo_comm_destroy(self._handle), "dgppo_comm_destroy")
+            self._handle = C.c_void_p()
+
+
+def make_allreduce(world: int, backend: str = "rccl"):
+    """-> (allreduce(flat) or None, closer()).  backend "rccl": the C-ABI communicator; "gloo": torch.distributed on the
+    control-plane group (rehearsals on one GPU / CPU tests).  The callable SUMS in place; the engine divides by `world`
+    inside the optimiser kernel (`grad_scale`), so there is no scaling pass here."""
     if world <= 1:
-        return None
+        return None, (lambda: None)
     import torch.distributed as dist
+    rank, _ = init_control_plane()
+    if backend == "rccl":
+        comm = RcclComm(rank, world)
+        return comm.allreduce_sum, comm.destroy
+    if backend != "gloo":
+        raise ValueError(f"unknown data-plane backend '{backend}' (rccl | gloo)")
 
     def allreduce(flat: torch.Tensor):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / world)
-    return allreduce
+    return allreduce, (lambda: None)
 
 
 def shard_seeds(rank: int, B_local: int, iteration: int, run_seed: int = 0) -> np.ndarray:
@@ -47,10 +95,23 @@ def shard_seeds(rank: int, B_local: int, iteration: int, run_seed: int = 0) -> n
     return (s ^ np.uint64(run_seed) ^ np.uint64((iteration * 7919 + 1) & 0xFFFFFFFF)).view(np.int64)
 
 
-def max_over_ranks(x: float, world: int, device) -> float:
+def barrier(world: int) -> None:
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(x: float, world: int) -> float:
     if world <= 1:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown(world: int) -> None:
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()

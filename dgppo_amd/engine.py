@@ -93,7 +93,7 @@ class OptState:
 
 class Engine:
     def __init__(self, cfg: N.EnvCfg, hyper: Hyper, device, T: int = 128,
-                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, prepass_graphs: int = 1 << 16,
+                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, world: int = 1, prepass_graphs: int = 1 << 16,
                  use_graphs: bool = False, multi_stream: bool = False, algo: str = "dgppo"):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
         assert algo in ("dgppo", "informarl", "hcbfcrpo"), algo
@@ -107,18 +107,36 @@ class Engine:
         self._side_streams = None
         self._ro_cache: Dict[tuple, dict] = {}
         self.n_cost = 2
-        self.policy = nets.Net("policy", cfg, hyper.actor_gnn_layers, 2, device)
-        self.Vl = nets.Net("Vl", cfg, hyper.Vl_gnn_layers, 1, device)
-        self.Vh = nets.Net("Vh", cfg, hyper.Vh_gnn_layers, self.n_cost, device) if algo == "dgppo" else None
+        # ONE flat fp32 buffer [g_policy | g_Vl | g_Vh | scalars]: each network's gradient buffer is a
+        # 16-byte-aligned slice of it and the loss/metric sums of the minibatch (stats rows 0..2) sit at its tail, so the
+        # data-parallel update needs a single all-reduce per minibatch.  Row 3 of the stats (the per-iteration safe count)
+        # lies outside the reduced range.
+        spec = [("policy", hyper.actor_gnn_layers, 2), ("Vl", hyper.Vl_gnn_layers, 1)]
+        if algo == "dgppo":
+            spec.append(("Vh", hyper.Vh_gnn_layers, self.n_cost))
+        sizes = [nets.make_layout(k, cfg.node_dim, layers, n_out).size for k, layers, n_out in spec]
+        offs, tot = [], 0
+        for sz in sizes:
+            offs.append(tot)
+            tot += (sz + 3) // 4 * 4
+        self.flat_grads = torch.zeros(tot + 4 * 8, device=device)
+        self.n_reduced = tot + 3 * 8
+        self.stats = self.flat_grads[tot:tot + 32].view(4, 8)
+        built = {k: nets.Net(k, cfg, layers, n_out, device, grads=self.flat_grads[o:o + sz])
+                 for (k, layers, n_out), o, sz in zip(spec, offs, sizes)}
+        self.policy, self.Vl, self.Vh = built["policy"], built["Vl"], built.get("Vh")
         self.opt = {k: OptState(net.layout.size, device) for k, net in self.nets.items()}
         self.arena = nets.Arena(device)
+        # allreduce(flat): in-place SUM over the data-parallel ranks of the flat buffer above (dgppo_comm_allreduce_sum_f32 on
+        # the caller's stream); the 1/world is applied inside dgppo_clip_adam_step (grad_scale), not by a separate pass
         self.allreduce = allreduce
+        self.world = int(world)
+        assert self.world >= 1 and (allreduce is not None or self.world == 1), "world > 1 needs an allreduce"
         self.prepass_graphs = prepass_graphs
         self.ray_cos, self.ray_sin = (OE.ray_tables(cfg.n_rays, device) if cfg.is_lidar else (None, None))
         self.lam_pow = OA.lam_pow_table(hyper.gae_lambda, T, device)
         # the constant entropy noise of SURVEY A.7 (distribution.py:40: seed drawn once at trace time)
         self.eps_hat = torch.zeros(cfg.n_agents, 2, device=device)
-        self.stats = torch.zeros(4, 8, device=device)
         self.grad_hook: Optional[Callable[[str, nets.Net, int], None]] = None   # (net name, net, minibatch) before the optimiser
         self._mb = 0
 
@@ -191,18 +209,23 @@ class Engine:
             slot["graph"] = None                               # a scratch buffer moved: the captured pointers are stale
         if slot["graph"] is not None:
             slot["graph"].replay()
+            K.FLOPS[0] += slot.get("flops", 0.0)               # the replayed launches never pass through the Python wrappers
             return ro
         # first call (or stale graph): eager launches — they also size every scratch buffer — then capture the same loop
         # right away, so that the second call already replays (one warm-up iteration is enough for steady state)
+        f0 = K.FLOPS[0]
         self._rollout_steps(ro, eps, B, stochastic)
+        slot["flops"] = K.FLOPS[0] - f0
         if not slot.get("failed", False):
             graph = torch.cuda.CUDAGraph()
             try:
                 # thread-local error mode: other threads (the RCCL watchdog of torch.distributed) keep issuing HIP calls
                 # while this thread captures; in the default global mode those would invalidate the capture.
                 # Capturing records the launches without executing them: the results of the eager pass above stand.
+                f1 = K.FLOPS[0]
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._rollout_steps(ro, eps, B, stochastic)
+                K.FLOPS[0] = f1 + slot["flops"]                 # capture records, the replay below executes once
                 slot["graph"], slot["gen"] = graph, self._arena_generation()
                 # the first launch of a ~2300-node graph uploads it to the device (~100 ms): pay that here, in the same
                 # warm-up call (same inputs, so it rewrites the record with identical values)
@@ -349,12 +372,13 @@ class Engine:
         return self._side_streams
 
     def _opt_step(self, name: str, lr: float):
+        """NaN check -> norm -> clip -> Adam on one network (trainer/utils.py:89-118 + optax); in the data-parallel path the
+        gradients were summed over the ranks just before and are read as g / world."""
         net, opt = self.nets[name], self.opt[name]
-        if self.allreduce is not None:
-            self.allreduce(net.grads)
         if self.grad_hook is not None:
             self.grad_hook(name, net, self._mb)
-        OA.clip_adam_step(net.params, net.grads, opt.m, opt.v, opt.state, lr, self.hp.max_grad_norm)
+        OA.clip_adam_step(net.params, net.grads, opt.m, opt.v, opt.state, lr, self.hp.max_grad_norm,
+                          grad_scale=1.0 / self.world)
         net.prepare()
 
     def targets(self, ro: RolloutData, det: RolloutData, step: int):
@@ -394,6 +418,7 @@ class Engine:
         R = G * n
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         side = self._net_streams() if (self.multi_stream and main is not None) else None
+        reduce = self.allreduce is not None
         for mb in range(n_mb):
             idx = idx_all[mb * Eb:(mb + 1) * Eb]
             idx32 = idx.to(torch.int32)
@@ -416,7 +441,8 @@ class Engine:
                 K.value_loss(act["v"], Ql_mb.view(G, 1), dv, self.stats[0])
                 self.Vl.zero_grads()
                 self.Vl.backward(act, dv)
-                self._opt_step("Vl", hp.lr_Vl)
+                if not reduce:
+                    self._opt_step("Vl", hp.lr_Vl)
 
             def update_Vh():      # dgppo.py:296-321: the deterministic rollout with its stored carry
                 act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det, tag="tr")
@@ -424,7 +450,8 @@ class Engine:
                 K.value_loss(act["v"], Qh_det_mb, dvh, self.stats[1])
                 self.Vh.zero_grads()
                 self.Vh.backward(act, dvh)
-                self._opt_step("Vh", hp.lr_Vh)
+                if not reduce:
+                    self._opt_step("Vh", hp.lr_Vh)
 
             def update_policy():  # informarl.py:405-457
                 act = self.policy.forward(feats, n_seq=Eb * C * n, T=hp.rnn_step, h0=None, tag="tr")
@@ -435,7 +462,8 @@ class Engine:
                               self.stats[2], hp.clip_eps, hp.coef_ent)
                 self.policy.zero_grads()
                 self.policy.backward(act, dms)
-                self._opt_step("policy", hp.lr_actor)
+                if not reduce:
+                    self._opt_step("policy", hp.lr_actor)
 
             if informarl:
                 update_Vh = lambda: None                       # noqa: E731  (no constraint-value network)
@@ -451,13 +479,23 @@ class Engine:
                         fn()
                 for st in side:
                     main.wait_stream(st)
+            if reduce:
+                # data-parallel exchange: ONE all-reduce(sum) of [g_policy | g_Vl | g_Vh | loss sums] per
+                # minibatch once the three backward passes have joined, then every rank applies the identical
+                # NaN-check -> norm -> clip -> Adam (replicas stay bit-identical)
+                self.allreduce(self.flat_grads[:self.n_reduced])
+                self._opt_step("Vl", hp.lr_Vl)
+                if not informarl:
+                    self._opt_step("Vh", hp.lr_Vh)
+                self._opt_step("policy", hp.lr_actor)
         self._last = dict(Ql_mb=Ql_mb, G=G, R=R, nh=nh, B=B)
         return self.info(ro)
 
     def info(self, ro: RolloutData) -> dict:
         """scalars of the LAST minibatch (dgppo.py:292) with the reference's key names; one host sync."""
         L = self._last
-        s = self.stats.cpu().numpy()
+        s = self.stats.cpu().numpy().copy()
+        s[:3] /= self.world                                   # rows 0..2 were summed over the ranks with the gradients
         G, R, nh, B = L["G"], L["R"], L["nh"], L["B"]
         o = {k: self.opt[k].state.cpu().numpy() for k in self.opt}
         pol_loss = s[2, 0] / R - self.hp.coef_ent * s[2, 1] / R

@@ -117,12 +117,17 @@ class GraphFeats:
 class Net:
     """One network = flat params + flat grads + prepared GNN weights + forward/backward over a batch of graphs."""
 
-    def __init__(self, kind: str, cfg: N.EnvCfg, gnn_layers: int, n_out: int, device):
+    def __init__(self, kind: str, cfg: N.EnvCfg, gnn_layers: int, n_out: int, device, grads: Optional[torch.Tensor] = None):
+        """grads: optional caller-owned flat gradient buffer (a slice of the engine's [g_policy | g_Vl | g_Vh | scalars]
+        buffer, so that the data-parallel update all-reduces ALL gradients with one collective)."""
         assert kind in ("policy", "Vl", "Vh")
         self.kind, self.cfg, self.gnn_layers, self.n_out, self.device = kind, cfg, gnn_layers, n_out, device
         self.layout = make_layout(kind, cfg.node_dim, gnn_layers, n_out)
         self.params = torch.zeros(self.layout.size, device=device)
-        self.grads = torch.zeros(self.layout.size, device=device)
+        if grads is None:
+            grads = torch.zeros(self.layout.size, device=device)
+        assert grads.shape == (self.layout.size,) and grads.is_contiguous() and grads.data_ptr() % 16 == 0
+        self.grads = grads
         self.arena = Arena(device)
         self._views: Dict[tuple, torch.Tensor] = {}
         # per-layer dims: F (true input width), Fp (padded), D, Kp

@@ -9,6 +9,11 @@ import torch
 
 from . import _native as N
 
+# Matrix-core work actually enqueued, in flops (2 per multiply-add of the UNPADDED operand shapes), accumulated by the
+# wrappers below; bench.py reads it to report MFMA utilisation from executed work rather than from SURVEY's per-node
+# estimate.  (Host-side bookkeeping only; the engine re-adds a rollout's count when it replays a captured HIP graph.)
+FLOPS = [0.0]
+
 
 def _mat(t: torch.Tensor, name: str):
     """2-D fp32 CUDA tensor with unit inner stride -> (ptr, ld, rows, cols)."""
@@ -38,6 +43,7 @@ def dense_fwd(X, W, bias, Y, act: int = 0, accumulate: bool = False, trans_w: bo
         raise ValueError(f"dense_fwd: shape mismatch X{tuple(X.shape)} W{tuple(W.shape)} trans={trans_w} Y{tuple(Y.shape)}")
     if bias is not None:
         N.expect_shape(bias, (Ncol,), "bias")
+    FLOPS[0] += 2.0 * M * K * Ncol
     rc = N.lib().dgppo_dense_fwd(xp, ldx, wp, ldw, _p(bias, "bias"), yp, ldy, M, K, Ncol, int(act), int(accumulate),
                                  int(trans_w), N.stream_ptr())
     N.check(rc, "dgppo_dense_fwd")
@@ -57,6 +63,7 @@ def mlp_gi_fwd(X, W1, b1, g1, be1, W2, b2, g2, be2, Wi, bi, gi, saves=None):
         for t, shp, nm in zip(saves, ((M, 64), (M, 64), (M, 2), (M, 64), (M, 64), (M, 2)), ("p1", "y1", "st1", "p2", "y2", "st2")):
             N.expect_shape(t, shp, nm)
         sv = list(saves)
+    FLOPS[0] += 2.0 * M * (64 * 64 * 2 + 64 * 192)
     rc = N.lib().dgppo_mlp_gi_fwd(xp, ldx, _p(W1), _p(b1), _p(g1), _p(be1), _p(W2), _p(b2), _p(g2), _p(be2), _p(Wi), _p(bi),
                                   *[_p(t) for t in sv], _p(gi), M, N.stream_ptr())
     N.check(rc, "dgppo_mlp_gi_fwd")
@@ -78,6 +85,7 @@ def gru1_head_fwd(gi, Wh, bhn, h0, W1, b1, W2, b2, hs, hprev, gates, u, out):
     for t, shp, nm in ((hprev, (M, 64), "hprev"), (gates, (M, 256), "gates"), (u, (M, 64), "u")):
         if t is not None:
             N.expect_shape(t, shp, nm)
+    FLOPS[0] += 2.0 * M * (64 * 192 + (64 * 64 + 64 * n_out if W2 is not None else 64 * n_out))
     rc = N.lib().dgppo_gru1_head_fwd(_p(gi), _p(Wh), _p(bhn), _p(h0), _p(W1), _p(b1), _p(W2), _p(b2), _p(hs), _p(hprev),
                                      _p(gates), _p(u), _p(out), M, n_out, N.stream_ptr())
     N.check(rc, "dgppo_gru1_head_fwd")
@@ -109,6 +117,7 @@ def dense_bwd_w(X, dY, dW, db=None):
     if db is not None:
         N.expect_shape(db, (Ncol,), "db")
     ws = _bwd_w_workspace(X.device, K, Ncol)
+    FLOPS[0] += 2.0 * M * K * Ncol
     rc = N.lib().dgppo_dense_bwd_w(xp, ldx, yp, ldy, wp, ldw, _p(db, "db"), M, K, Ncol, _p(ws, "workspace"),
                                    C.c_int64(ws.numel() * 4), N.stream_ptr())
     N.check(rc, "dgppo_dense_bwd_w")
@@ -140,6 +149,7 @@ def attn_fwd(cfg, F, H, Kp, qt, Xa, Xo, efeat, emask, zcat, attn, G):
     N.expect_shape(Xa, (G * n, F), "Xa")
     N.expect_shape(zcat, (G * n, Kp), "zcat")
     N.expect_shape(attn, (G * n, S, H), "attn")
+    FLOPS[0] += 2.0 * G * n * H * S * (2 * F + 4)            # logits (F) + aggregation of [x_s | e] (F + 4) per (agent, head, slot)
     rc = N.lib().dgppo_attn_fwd(C.byref(cfg), F, H, Kp, _p(qt), _p(Xa), _p(Xo), _p(efeat), _p(emask), _p(zcat), _p(attn),
                                 G, N.stream_ptr())
     N.check(rc, "dgppo_attn_fwd")
@@ -151,6 +161,7 @@ def attn_bwd(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo, efeat, dqt, dXa, dXo, G):
     N.expect_shape(dqt, (G * n, H * F), "dqt")
     if dXa is not None:
         N.expect_shape(dXa, (G * n, F), "dXa")
+    FLOPS[0] += 4.0 * G * n * H * cfg.fan_in * (2 * F + 4)   # dA, dL -> dqt, dXs: twice the forward contractions
     rc = N.lib().dgppo_attn_bwd(C.byref(cfg), F, H, Kp, _p(dzcat), _p(attn), _p(qt), _p(Xa), _p(Xo), _p(efeat), _p(dqt),
                                 _p(dXa), _p(dXo), G, N.stream_ptr())
     N.check(rc, "dgppo_attn_bwd")
@@ -190,6 +201,7 @@ def gru_fwd(gi, Wh, bhn, h0, hs, hprev, gates, n_seq, T, n_inner):
     N.expect_shape(Wh, (64, 192), "Wh")
     if h0 is not None:
         N.expect_shape(h0, (n_seq, 64), "h0")
+    FLOPS[0] += 2.0 * rows * 64 * 192
     rc = N.lib().dgppo_gru_fwd(_p(gi), _p(Wh), _p(bhn), _p(h0), _p(hs), _p(hprev), _p(gates), n_seq, T, n_inner,
                                N.stream_ptr())
     N.check(rc, "dgppo_gru_fwd")
@@ -200,6 +212,7 @@ def gru_bwd(dhs, Wh, hprev, gates, dgi, dgh, n_seq, T, n_inner):
     N.expect_shape(dhs, (rows, 64), "dhs")
     N.expect_shape(dgi, (rows, 192), "dgi")
     N.expect_shape(dgh, (rows, 192), "dgh")
+    FLOPS[0] += 2.0 * rows * 64 * 192
     rc = N.lib().dgppo_gru_bwd(_p(dhs), _p(Wh), _p(hprev), _p(gates), _p(dgi), _p(dgh), n_seq, T, n_inner, N.stream_ptr())
     N.check(rc, "dgppo_gru_bwd")
 

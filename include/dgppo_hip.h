@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGPPO_ABI_VERSION 1
+#define DGPPO_ABI_VERSION 2
 
 /* environment kinds — dgppo/env/__init__.py:9-23 (registered ids on the hot path) */
 enum {
@@ -248,9 +248,25 @@ int32_t dgppo_shaped_reward(const float* reward, const float* cost, float cost_w
                             int32_t n, int32_t nh, void* stream);
 /* compute_norm_and_clip + has_any_nan_or_inf (dgppo/trainer/utils.py:89-118) and optax.apply_if_finite(adam)
  * (dgppo/algo/informarl.py:131-137) on one flat buffer.  state [8] lives on the device:
- * [0..1] scratch, [2] adam count, [3] total steps, [4] last grad norm, [5] last non-finite flag.                   */
+ * [0..1] scratch, [2] adam count, [3] total steps, [4] last grad norm, [5] last non-finite flag.
+ * grad_scale multiplies every gradient entry as it is read (norm, non-finite test and update all see g * grad_scale):
+ * 1 for a single device, 1/world after dgppo_comm_allreduce_sum_f32 (the mean of equal-sized shards' gradients is the
+ * gradient of the global mean loss), so the data-parallel path needs no separate scaling pass.                       */
 int32_t dgppo_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float* state, float lr,
-                             float b1, float b2, float eps, float max_norm, void* stream);
+                             float b1, float b2, float eps, float max_norm, float grad_scale, void* stream);
+
+/* ---- C1: gradient exchange over RCCL / xGMI (no reference counterpart: the reference is single-device, SURVEY F2;
+ * this is jax.lax.pmean of the gradient trees of a pmap'ed update_inner, dgppo/algo/dgppo.py:188-294) -------------- */
+#define DGPPO_COMM_ID_BYTES 128
+/* rank 0: a fresh rendezvous id (ncclGetUniqueId); the caller ships the 128 bytes to the other ranks out of band.   */
+int32_t dgppo_comm_unique_id(uint8_t* id_out);
+/* every rank, after selecting its HIP device: join the communicator (ncclCommInitRank).  *comm_out is an opaque
+ * handle owned by the library until dgppo_comm_destroy.  Collective: blocks until all `world` ranks have called it. */
+int32_t dgppo_comm_init(const uint8_t* id, int32_t rank, int32_t world, void** comm_out);
+/* in-place all-reduce(sum) of buf[count] fp32 (DEVICE pointer) enqueued on `stream`; never synchronises the host.
+ * One call per minibatch on the flat [g_policy | g_Vl | g_Vh | scalars] buffer.                        */
+int32_t dgppo_comm_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);
+int32_t dgppo_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -66,3 +66,20 @@ def test_product_path_refuses_cpu_tensors():
     from dgppo_amd import _native as N
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         N.ptr(torch.zeros(3))
+
+
+def test_comm_entry_points_validate_without_a_gpu():
+    """C1 (include/dgppo_hip.h): bad handles / NULL arguments are refused on the host, before RCCL is even looked up"""
+    from dgppo_amd import _native as N
+    lib = N.lib()
+    assert lib.dgppo_comm_allreduce_sum_f32(None, None, C.c_int64(4), None) == -1
+    assert b"not a communicator" in lib.dgppo_last_error()
+    bogus = (C.c_uint8 * 64)()
+    assert lib.dgppo_comm_allreduce_sum_f32(bogus, None, C.c_int64(4), None) == -1
+    assert lib.dgppo_comm_destroy(None) == 0
+    assert lib.dgppo_comm_destroy(bogus) == -1
+    assert lib.dgppo_comm_unique_id(None) == -1
+    handle = C.c_void_p()
+    assert lib.dgppo_comm_init(None, 0, 1, C.byref(handle)) == -1
+    idb = (C.c_uint8 * 128)()
+    assert lib.dgppo_comm_init(idb, 3, 2, C.byref(handle)) == -1 and b"outside world" in lib.dgppo_last_error()

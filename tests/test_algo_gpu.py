@@ -38,9 +38,14 @@ def test_advantage(cuda):
     stats = torch.zeros(8, device=cuda)
     O.advantage(d(Ql), d(Vl), d(Vh), 0.03, 10.0, 1e-2, 2.0, adv, stats)
     got = adv.cpu().numpy()
-    # the safe gate is a hard threshold on a fp32 quantity: allow a handful of borderline flips, everything else 1e-5
+    # The safe gate is a hard threshold on the fp32 quantity cdot = (Vh[t+1]-Vh[t])/dt + alpha*Vh[t] (dgppo.py:246-251).
+    # Gate flips and numeric error are counted SEPARATELY: a flip is legitimate only where |cdot| is at rounding level
+    # (the kernel and numpy may round cdot differently by an ulp); every other entry must agree to 1e-5.
+    deriv = (Vh[:, 1:] - Vh[:, :-1]) / np.float32(0.03) + np.float32(10.0) * Vh[:, :-1]
+    rounding_level = (np.abs(deriv) < 1e-5).any(axis=-1)
     bad = np.abs(got - want) > 1e-5 * np.maximum(1, np.abs(want))
-    assert bad.mean() < 1e-3, bad.mean()
+    assert not (bad & ~rounding_level).any(), "numeric error above 1e-5 away from the gate threshold"
+    assert (bad & rounding_level).sum() <= 4, "gate flips at the threshold should be a handful at most"
     assert abs(stats[0].item() / (B * T * n) - safe) < 1e-3
     assert 0.05 < safe < 0.95
 

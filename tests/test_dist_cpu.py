@@ -54,20 +54,27 @@ def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     torch.set_num_threads(2)
     from dgppo_amd import dist as D
-    r, w = D.init(backend="gloo")
+    r, w = D.init_control_plane()
     assert (r, w) == (rank, world)
-    ar = D.make_allreduce(w)
+    ar, close = D.make_allreduce(w, backend="gloo")
     shard = [[0, 1], [2, 3]][rank]                       # equal-sized shards of the 4-env minibatch
     g = _grads_on(shard)
-    for k in g:
-        ar(g[k])
-    t = D.max_over_ranks(float(rank + 1), w, torch.device("cpu"))
+    # the engine's layout: ONE flat buffer [g_policy | g_Vl | g_Vh], one collective, 1/world applied by the optimiser
+    keys = sorted(g)
+    flat = torch.cat([g[k] for k in keys])
+    ar(flat)
+    flat = flat * (1.0 / w)                              # what dgppo_clip_adam_step's grad_scale does on the device
+    off = 0
+    for k in keys:
+        g[k] = flat[off:off + g[k].numel()].clone()
+        off += g[k].numel()
+    t = D.max_over_ranks(float(rank + 1), w)
     assert t == float(world)
     if rank == 0:
         torch.save(g, out)
-    import torch.distributed as dist
-    dist.barrier()
-    dist.destroy_process_group()
+    D.barrier(w)
+    close()
+    D.shutdown(w)
 
 
 def test_gradient_allreduce_equals_full_batch(tmp_path):
@@ -88,4 +95,4 @@ def test_shard_seeds_depend_on_global_index_only():
     halves = np.concatenate([D.shard_seeds(0, 4, 3), D.shard_seeds(1, 4, 3)])
     np.testing.assert_array_equal(whole, halves)
     assert len(set(whole.tolist())) == 8 and not np.array_equal(whole, D.shard_seeds(0, 8, 4))
-    assert D.make_allreduce(1) is None
+    assert D.make_allreduce(1)[0] is None

@@ -1,5 +1,8 @@
 """End-to-end GPU parity of the DGPPO engine (rollout -> value pre-passes -> GAE -> advantage -> minibatch gradients)
 against the torch/numpy oracle, on small configurations; plus rollout-level checks."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +12,7 @@ from oracle import env_np as E
 from oracle import nn_torch as T
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _np_rollout(ro):
@@ -17,13 +21,13 @@ def _np_rollout(ro):
                 log_pis=c(ro.log_pis), rnn_states=c(ro.rnn_states.contiguous()), rewards=c(ro.rewards), costs=c(ro.costs))
 
 
-def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step):
+def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step, **engine_kw):
     from dgppo_amd import _native as N, engine as EN, init
     kind = N.ENV_KINDS[kind_name]
     cfg = N.make_env_cfg(kind, n, n_obs)
     ocfg = E.EnvCfg(kind, n_agents=n, n_obs=n_obs)
     hp = EN.Hyper(batch_size=batch_size, rnn_step=rnn_step, train_steps=100)
-    eng = EN.Engine(cfg, hp, cuda, T=T_)
+    eng = EN.Engine(cfg, hp, cuda, T=T_, **engine_kw)
     trees = {"policy": init.init_policy(0, cfg.node_dim, 2, 2), "Vl": init.init_value(0, cfg.node_dim, 1, 2, 2),
              "Vh": init.init_value(0, cfg.node_dim, 2, 1, 3)}
     rng = np.random.default_rng(11)
@@ -34,6 +38,60 @@ def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step):
         net.load_tree(trees[k])
     eng.set_entropy_noise(77)
     return cfg, ocfg, hp, eng, trees
+
+
+def _close(got, want, name, tol=1e-5):
+    """north_star's fp32 bar: |got - want| <= 1e-5 of the output scale"""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= tol * scale, f"{name}: max error {err:.3e} > {tol:g} x scale {scale:.3g}"
+
+
+def _check_advantage(tg, wt, dt, alpha, cbf_eps, w, label=""):
+    """The advantage merge has a HARD gate (safe = all_h(cdot <= 0), dgppo.py:246-259) on cdot = (Vh[t+1]-Vh[t])/dt + alpha*Vh[t],
+    which amplifies any fp32 difference in Vh by 1/dt + alpha ~ 43.  Three separate statements instead of one loose one:
+      (1) the advantage KERNEL on the device's own Vl / Vh / Ql equals the oracle formula on those same inputs to 1e-5,
+          gate flips allowed only where |cdot| is at rounding level (< 1e-5) and counted;
+      (2) end to end, a gate differs from the oracle's only where the oracle's own |cdot| is inside the propagated error
+          band of Vh (a borderline decision), and such flips are rare;
+      (3) end to end, every entry whose gate agrees is within the propagated numeric bound."""
+    from oracle import algo_ref as A
+    g = {k: tg[k].cpu().numpy() for k in ("Vl", "Vh", "Ql", "adv")}
+    # (1) same inputs
+    same_in, _ = A.advantage(g["Ql"], g["Vl"], g["Vh"], dt, alpha, cbf_eps, w)
+    deriv_g = (g["Vh"][:, 1:] - g["Vh"][:, :-1]) / np.float32(dt) + np.float32(alpha) * g["Vh"][:, :-1]
+    rounding_level = (np.abs(deriv_g) < 1e-5).any(axis=-1)
+    bad1 = np.abs(g["adv"] - same_in) > 1e-5 * np.maximum(1, np.abs(same_in))
+    assert not (bad1 & ~rounding_level).any(), f"{label}: advantage kernel off by more than 1e-5 on identical inputs"
+    # (2) gate decisions end to end
+    errVh = float(np.abs(g["Vh"] - wt["Vh"]).max())
+    band = errVh * (2.0 / dt + alpha) + 1e-6
+    deriv_o = (wt["Vh"][:, 1:] - wt["Vh"][:, :-1]) / np.float32(dt) + np.float32(alpha) * wt["Vh"][:, :-1]
+    safe_g, safe_o = (deriv_g <= 0).all(axis=-1), (deriv_o <= 0).all(axis=-1)
+    flipped = safe_g != safe_o
+    borderline = (np.abs(deriv_o) <= band).any(axis=-1)
+    assert not (flipped & ~borderline).any(), f"{label}: a safe-gate decision differs away from the threshold (band {band:.2e})"
+    assert flipped.mean() < 0.02, f"{label}: {flipped.sum()} of {flipped.size} gates flipped"
+    # (3) numeric error where the gate agrees: d(adv) <= d(Al) + w * d(cdot)
+    Al_o = wt["Ql"] - wt["Vl"][:, :-1]
+    std = Al_o.std(axis=1, keepdims=True) + 1e-8
+    errAl = (np.abs(g["Ql"] - wt["Ql"]).max() + np.abs(g["Vl"] - wt["Vl"]).max()) * 4.0 / std
+    bound = errAl[:, :, None] + w * band + 1e-5
+    err = np.abs(g["adv"] - wt["adv"])
+    assert (err[~flipped] <= np.broadcast_to(bound, err.shape)[~flipped]).all(), \
+        f"{label}: advantage error {err[~flipped].max():.2e} exceeds the propagated bound"
+    return int(flipped.sum())
+
+
+def _check_first_minibatch_grads(leaf, grads, names, tol=5e-5):
+    for name in names:
+        w = dict(T.tree_leaves(T.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), leaf[name])))
+        gt = dict(T.tree_leaves(T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), grads[name])))
+        scale = max(float(v.abs().max()) for v in w.values())
+        for k in w:
+            err = float((gt[k].double() - w[k].double()).abs().max())
+            assert err <= tol * max(scale, 1e-3), f"{name} grad {k}: err {err:.3e} scale {scale:.3e}"
 
 
 @pytest.mark.parametrize("kind,n,n_obs", [("LidarSpread", 3, 2), ("MPETarget", 3, 0)])
@@ -61,7 +119,7 @@ def test_rollout_matches_oracle_stepwise(cuda, kind, n, n_obs):
             with torch.no_grad():
                 if stochastic:
                     a, lp, h_new = T.policy_sample(trees["policy"], g, h, n, torch.from_numpy(eps[t]))
-                    np.testing.assert_allclose(r["log_pis"][:, t], lp.numpy(), atol=2e-5)
+                    _close(r["log_pis"][:, t], lp.numpy(), "log_pi")
                 else:
                     a, h_new = T.policy_mode(trees["policy"], g, h, n)
             np.testing.assert_allclose(r["actions"][:, t], a.numpy(), atol=1e-5)
@@ -94,9 +152,8 @@ def test_update_targets_and_gradients(cuda, kind, n, n_obs):
     wt = R.targets(leaf, ocfg, r, d, hpd, eng.cbf_weight_at(step))
     assert eng.cbf_weight_at(step) == 2.0
     for k in ("Vl", "Vh", "Vh_det", "Ql", "Qh", "Qh_det"):
-        np.testing.assert_allclose(tg[k].cpu().numpy(), wt[k], atol=2e-5, err_msg=k)
-    got_adv = tg["adv"].cpu().numpy()
-    assert (np.abs(got_adv - wt["adv"]) > 1e-4 * np.maximum(1, np.abs(wt["adv"]))).mean() < 0.02   # hard safe-gate flips
+        _close(tg[k], wt[k], k)
+    _check_advantage(tg, wt, ocfg.dt, hp.alpha, hp.cbf_eps, eng.cbf_weight_at(step), kind)
     # gradients of the FIRST minibatch (before any optimiser step) and its logged scalars
     perm = np.array([2, 0, 3, 1])
     grads = {}
@@ -110,13 +167,7 @@ def test_update_targets_and_gradients(cuda, kind, n, n_obs):
     tg_np = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in tg.items()}
     want = R.minibatch_losses(leaf, ocfg, r, d, tg_np, perm[:Eb], hpd, eng.eps_hat.cpu())
     info = eng.update(ro, det, step, perm)
-    for name in ("Vl", "Vh", "policy"):
-        w = dict(T.tree_leaves(T.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), leaf[name])))
-        gt = dict(T.tree_leaves(T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), grads[name])))
-        scale = max(float(v.abs().max()) for v in w.values())
-        for k in w:
-            err = float((gt[k].double() - w[k].double()).abs().max())
-            assert err <= 5e-5 * max(scale, 1e-3), f"{name} grad {k}: err {err:.3e} scale {scale:.3e}"
+    _check_first_minibatch_grads(leaf, grads, ("Vl", "Vh", "policy"))
     # info reports the LAST minibatch, after one optimiser step: loose tolerance, keys as in the reference
     for k in ("Vl/loss", "Vl/grad_norm", "Vl/has_nan", "Vl/max_target", "Vl/min_target", "Vh/loss_Vh", "Vh/grad_Vh_norm",
               "Vh/grad_Vh_has_nan", "policy/loss", "policy/grad_norm", "policy/has_nan", "policy/log_pi_min",
@@ -203,9 +254,18 @@ def test_informarl_targets_and_gradients(cuda):
     hpd = dict(gamma=hp.gamma, gae_lambda=hp.gae_lambda, rnn_step=rs, clip_eps=hp.clip_eps, coef_ent=hp.coef_ent)
     leaf = {k: T.tree_map(lambda t: t.clone().requires_grad_(), trees[k]) for k in ("policy", "Vl")}
     wt = R.targets_informarl(leaf, ocfg, r, hpd, w)
-    np.testing.assert_allclose(tg["Vl"].cpu().numpy(), wt["Vl"], atol=2e-5)
-    np.testing.assert_allclose(tg["Ql"].cpu().numpy(), wt["Ql"], atol=5e-5)
-    np.testing.assert_allclose(tg["adv"].cpu().numpy(), wt["adv"], atol=2e-3)       # standardised: error / std of 8 samples
+    _close(tg["Vl"], wt["Vl"], "Vl")
+    _close(tg["Ql"], wt["Ql"], "Ql")
+    # the advantage is standardised per env over T = 8 samples, which divides any input difference by std(Al):
+    # (1) the kernel on the device's own Ql / Vl against the formula (informarl.py:334-336) on the same inputs: 1e-5;
+    # (2) end to end: within the propagated bound 4 (dQl + dVl) / std
+    gQl, gVl, gadv = (tg[k].cpu().numpy() for k in ("Ql", "Vl", "adv"))
+    Al = gQl - gVl[:, :-1]
+    same_in = -((Al - Al.mean(1, keepdims=True)) / (Al.std(1, keepdims=True) + 1e-8))
+    _close(gadv, np.repeat(same_in[:, :, None], n, axis=-1), "advantage kernel on identical inputs")
+    Al_o = wt["Ql"] - wt["Vl"][:, :-1]
+    bound = 4.0 * (np.abs(gQl - wt["Ql"]).max() + np.abs(gVl - wt["Vl"]).max()) / (Al_o.std(1, keepdims=True) + 1e-8) + 1e-5
+    assert (np.abs(gadv - wt["adv"]) <= bound[:, :, None]).all()
     perm = np.array([2, 0, 3, 1])
     grads = {}
 
@@ -218,13 +278,7 @@ def test_informarl_targets_and_gradients(cuda):
     want = R.minibatch_losses(leaf, ocfg, r, None, tg_np, perm[:Eb], hpd, eng.eps_hat.cpu())
     info = eng.update(ro, None, step, perm)
     assert set(grads) == {"Vl", "policy"} and "Vh/loss_Vh" not in info and "Vh/loss_Vh" not in want
-    for name in ("Vl", "policy"):
-        wg = dict(T.tree_leaves(T.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), leaf[name])))
-        gt = dict(T.tree_leaves(T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), grads[name])))
-        scale = max(float(v.abs().max()) for v in wg.values())
-        for k in wg:
-            err = float((gt[k].double() - wg[k].double()).abs().max())
-            assert err <= 5e-5 * max(scale, 1e-3), f"{name} grad {k}: err {err:.3e} scale {scale:.3e}"
+    _check_first_minibatch_grads(leaf, grads, ("Vl", "policy"))
     for k in ("Vl/loss", "Vl/grad_norm", "policy/loss", "policy/entropy", "policy/clip_frac"):
         assert k in info and np.isfinite(info[k]), k
     assert float(eng.opt["policy"].state[2]) == B // Eb
@@ -255,9 +309,8 @@ def test_hcbfcrpo_targets_and_gradients(cuda, kind, n, n_obs):
     np.testing.assert_array_equal(tg["Vh"].cpu().numpy()[:, :T_], r["costs"])            # stored costs ARE get_cost(graph)
     np.testing.assert_allclose(tg["Vh"].cpu().numpy()[:, T_], wt["Vh"][:, T_], atol=1e-6)   # cost of next_graph[-1]
     for k in ("Vl", "Ql", "Qh"):
-        np.testing.assert_allclose(tg[k].cpu().numpy(), wt[k], atol=5e-5, err_msg=k)
-    got_adv = tg["adv"].cpu().numpy()
-    assert (np.abs(got_adv - wt["adv"]) > 2e-3 * np.maximum(1, np.abs(wt["adv"]))).mean() < 0.02      # hard safe-gate flips
+        _close(tg[k], wt[k], k)
+    _check_advantage(tg, wt, ocfg.dt, hp.alpha, hp.cbf_eps, 4.0, "hcbfcrpo " + kind)
     perm = np.array([2, 0, 3, 1])
     grads = {}
 
@@ -269,11 +322,99 @@ def test_hcbfcrpo_targets_and_gradients(cuda, kind, n, n_obs):
     tg_np = {k: v.cpu().numpy() for k, v in tg.items()}
     R.minibatch_losses(leaf, ocfg, r, None, tg_np, perm[:Eb], hpd, eng.eps_hat.cpu())
     info = eng.update(ro, None, step, perm)
-    for name in ("Vl", "policy"):
-        wg = dict(T.tree_leaves(T.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), leaf[name])))
-        gt = dict(T.tree_leaves(T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), grads[name])))
-        scale = max(float(v.abs().max()) for v in wg.values())
-        for k in wg:
-            err = float((gt[k].double() - wg[k].double()).abs().max())
-            assert err <= 5e-5 * max(scale, 1e-3), f"{name} grad {k}: err {err:.3e} scale {scale:.3e}"
+    _check_first_minibatch_grads(leaf, grads, ("Vl", "policy"))
     assert "eval/safe_data" in info and "Vh/loss_Vh" not in info and abs(info["eval/safe_data"] - wt["safe"]) < 0.05
+
+
+@pytest.mark.parametrize("kind,n,n_obs,B,T_,rs", [
+    ("LidarSpread", 8, 3, 8, 8, 4),            # BASELINE config 3/4 topology: N = 81 nodes, fan-in 24
+    ("LidarBicycleTarget", 16, 8, 5, 4, 2),    # BASELINE config 5 topology: N = 161 nodes, state_dim 5, node_dim 8
+])
+def test_full_topology_multi_block_prepass_targets_and_gradients(cuda, kind, n, n_obs, B, T_, rs):
+    """The engine exactly as training / bench.py runs it (HIP-graph rollouts, three-stream update) at the benchmark
+    TOPOLOGIES, with the value pre-passes forced into >= 3 env blocks with a ragged last one (`prepass_graphs`): at
+    B = 4096, T = 128 the default blocking is 9 blocks of 508 envs, so the e0 > 0 slices / strided bases of
+    Engine._block_feats and the reuse of the pre-pass scratch across blocks are on the path of every real run.
+    Vl / Vh / Vh_det / Ql / Qh / Qh_det and the first minibatch's gradients against the oracle (dgppo.py:204-229,
+    296-321; informarl.py:357-457), plus: the blocked result equals the single-block result (1e-6)."""
+    bs = 2 * T_ if B % 2 == 0 else T_                                       # envs per minibatch: 2 (or 1 when B is odd)
+    kw = dict(prepass_graphs=3 * (T_ + 1) + 1, use_graphs=True, multi_stream=True)
+    cfg, ocfg, hp, eng, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs, **kw)
+    block = eng.prepass_graphs // (T_ + 1)
+    assert block == 3 and B % block != 0 and -(-B // block) >= 2, "needs a ragged multi-block split"
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    # two calls each: the second one replays the captured HIP graph (the path training uses)
+    for _ in range(2):
+        ro, det = eng.rollout_pair(seeds, seeds + 1000, noise_seed=3)
+    torch.cuda.synchronize()
+    assert eng._ro_cache[(B, True)]["graph"] is not None
+    ro.finalize(); det.finalize()
+    step = 60
+    tg = eng.targets(ro, det, step)
+    # (a) blocked == single block (row-local kernels: blocking must not change a value beyond tile-variant rounding)
+    eng.prepass_graphs = 1 << 20
+    tg1 = eng.targets(ro, det, step)
+    for k in ("Vl", "Vh", "Vh_det", "Ql", "Qh", "Qh_det"):       # kernels pick tile variants by launch size: rounding-level only
+        _close(tg[k], tg1[k].cpu().numpy(), f"{k}: blocked vs single-block pre-pass", tol=1e-6)
+    eng.prepass_graphs = kw["prepass_graphs"]
+    # (b) against the oracle
+    hpd = dict(gamma=hp.gamma, gae_lambda=hp.gae_lambda, alpha=hp.alpha, cbf_eps=hp.cbf_eps, rnn_step=rs,
+               clip_eps=hp.clip_eps, coef_ent=hp.coef_ent)
+    r, d = _np_rollout(ro), _np_rollout(det)
+    leaf = {k: T.tree_map(lambda t: t.clone().requires_grad_(), v) for k, v in trees.items()}
+    w = eng.cbf_weight_at(step)
+    wt = R.targets(leaf, ocfg, r, d, hpd, w)
+    for k in ("Vl", "Vh", "Vh_det", "Ql", "Qh", "Qh_det"):
+        _close(tg[k], wt[k], k)
+    _check_advantage(tg, wt, ocfg.dt, hp.alpha, hp.cbf_eps, w, kind)
+    # (c) first-minibatch gradients through the three-stream update
+    perm = np.random.default_rng(2).permutation(B)
+    grads = {}
+
+    def hook(name, net, mb):
+        if mb == 0:
+            grads[name] = net.to_tree(net.grads)
+    eng.grad_hook = hook
+    Eb = bs // T_
+    tg_np = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in tg.items()}
+    R.minibatch_losses(leaf, ocfg, r, d, tg_np, perm[:Eb], hpd, eng.eps_hat.cpu())
+    info = eng.update(ro, det, step, perm)
+    torch.cuda.synchronize()
+    _check_first_minibatch_grads(leaf, grads, ("Vl", "Vh", "policy"))
+    assert info["Vl/has_nan"] == 0.0 and float(eng.opt["policy"].state[2]) == B // Eb
+
+
+def test_two_rank_update_allreduce_equals_full_minibatch(cuda, tmp_path):
+    """Engine(allreduce=..., world=2) as bench.py / train.py drive it, two ranks sharing this GPU over gloo
+    (tools/dist_rehearsal.py): the ONE all-reduced flat buffer [g_policy | g_Vl | g_Vh | loss sums] / world must equal
+    the single-process gradient on the union minibatch (mean of equal shards = global mean), the logged
+    losses must be the global means, and both replicas must hold bit-identical parameters after all optimiser steps."""
+    import socket
+    import subprocess
+    import sys as _sys
+    sys_path = os.path.join(ROOT, "tools", "dist_rehearsal.py")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
+    procs = [subprocess.Popen([_sys.executable, sys_path, "--rank", str(r), "--world", "2", "--port", str(port), "--out", outs[r]],
+                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    res = [torch.load(o, weights_only=True) for o in outs]
+    # single process, the same four envs, minibatch = all of them (batch_size x world)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dist_rehearsal as DR
+    eng = DR.build_engine(cuda, 1, None, shard_envs=4)
+    g1, p1, info1 = DR.run(eng, cuda, 4, [0, 1, 2, 3])
+    for name in ("policy", "Vl", "Vh"):
+        assert torch.equal(res[0]["grads"][name], res[1]["grads"][name]), f"{name}: ranks disagree on the reduced gradient"
+        assert torch.equal(res[0]["params"][name], res[1]["params"][name]), f"{name}: replicas diverged"
+        got = res[0]["grads"][name] / 2.0
+        scale = float(g1[name].abs().max())
+        err = float((got - g1[name]).abs().max())
+        assert err <= 2e-5 * max(scale, 1e-3), f"{name}: all-reduced mean gradient off by {err:.3e} (scale {scale:.3e})"
+    for k in ("Vl/loss", "Vh/loss_Vh", "policy/loss", "policy/entropy"):
+        assert abs(res[0]["info"][k] - res[1]["info"][k]) < 1e-7
+    # 2 ranks x 2 minibatches of 2 envs walk the same global minibatches as 1 process x 1 minibatch only at step 0:
+    # compare the FIRST step's logged quantities through a one-minibatch single-process run is not possible after two
+    # optimiser steps, so the loss check is on the replicas' agreement above and on finiteness here
+    assert all(np.isfinite(v) for v in res[0]["info"].values())
