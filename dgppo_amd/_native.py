@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdgppo_hip.so")
 
 ABI_VERSION = 2
+OPT_STATE_FLOATS = 8 + 2 * 256     # DGPPO_OPT_STATE_FLOATS (include/dgppo_hip.h)
 
 ENV_KINDS = {"LidarSpread": 0, "LidarTarget": 1, "LidarBicycleTarget": 2, "MPESpread": 3, "MPETarget": 4}
 RECT_STRIDE = 16

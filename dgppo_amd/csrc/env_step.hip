@@ -12,59 +12,8 @@
 //
 // Built with -ffp-contract=off: every fp32 operation is a single IEEE operation in the same order as
 // oracle/env_np.py, so states, rewards, costs, features and therefore all masks/indices are bit-identical.
-#include "common.h"
+#include "env_step.h"
 #include <stdlib.h>
-
-enum { MODE_STEP = 0, MODE_SENSE = 1, MODE_GRAPH = 2 };
-
-struct StepArgs {
-  dgppo_env_cfg cfg;
-  const float* agent;
-  const float* action;
-  const float* goal;
-  const float* obst;
-  const float* hits;
-  const float* ray_cos;
-  const float* ray_sin;
-  float* next_agent;
-  float* next_hits;
-  float* reward;
-  float* cost;
-  dgppo_graph_out g;
-  int has_graph;
-  int mode;
-  uint32_t rcp_n, rcp_k, rcp_no, rcp_no4;   // ceil(2^32 / d) for the index divisions of lidar_step_kernel (fdiv below)
-  int B;
-};
-
-// state2feat: lidar_bicycle_target.py:113-118 (identity for the double integrator)
-template <int SD>
-__device__ inline void state2feat(const float* s, float* f) {
-  if constexpr (SD == 5) {
-    f[0] = s[0];
-    f[1] = s[1];
-    f[2] = s[4] * s[2];
-    f[3] = s[4] * s[3];
-  } else {
-    f[0] = s[0]; f[1] = s[1]; f[2] = s[2]; f[3] = s[3];
-  }
-}
-
-__device__ inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
-
-// Rectangle.inside with radius r (obstacle.py:62-72); rec = 16-float record
-__device__ inline bool rect_inside(const float* rec, float px, float py, float r) {
-  float rel_x = px - rec[0];
-  float rel_y = py - rec[1];
-  float c = rec[5], s = rec[6];
-  float rel_xx = fabsf(rel_x * c + rel_y * s) - rec[2] / 2.0f;
-  float rel_yy = fabsf(rel_x * s - rel_y * c) - rec[3] / 2.0f;
-  bool is_in_down = (rel_xx < r) && (rel_yy < 0.0f);
-  bool is_in_up = (rel_xx < 0.0f) && (rel_yy < r);
-  bool is_out_corner = (rel_xx > 0.0f) && (rel_yy > 0.0f);
-  bool is_in_circle = sqrtf(rel_xx * rel_xx + rel_yy * rel_yy) < r;
-  return is_in_down || is_in_up || (is_out_corner && is_in_circle);
-}
 
 template <int SD>
 __global__ void env_step_kernel(StepArgs a) {
@@ -194,7 +143,7 @@ __global__ void env_step_kernel(StepArgs a) {
         }
         float c0 = (agent_cost <= 0.0f) ? agent_cost - 0.5f : agent_cost + 0.5f;
         float c1 = (obs_cost <= 0.0f) ? obs_cost - 0.5f : obs_cost + 0.5f;
-        if (lidar) { c0 = clampf(c0, -1.0f, 1.0f); c1 = clampf(c1, -1.0f, 1.0f); }
+        if (lidar) { c0 = clampf_nan(c0, -1.0f, 1.0f); c1 = clampf_nan(c1, -1.0f, 1.0f); }
         else { c0 = fmaxf(c0, -1.0f); c1 = fmaxf(c1, -1.0f); }   // mpe/base.py:189 clips only from below
         a.cost[((size_t)b * n + i) * 2] = c0;
         a.cost[((size_t)b * n + i) * 2 + 1] = c1;
@@ -436,7 +385,6 @@ extern "C" int32_t dgppo_debug_stamps(unsigned long long* out) {
 #else
 #define STAMP(i)
 #endif
-#define MISS_BITS 0x49742400u  // bits of 1e6f
 
 // x / d for 0 <= x < 2^16 and 1 <= d < 2^16 with rcp = ceil(2^32 / d): one v_mul_hi_u32 instead of the ~35-instruction
 // integer division sequence (exact: the error term x * (rcp*d - 2^32) stays below 2^32).
@@ -578,7 +526,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(80))) lidar
       const float agent_cost = c.two_car_radius - md, obs_cost = c.car_radius - mo;
       const float c0 = (agent_cost <= 0.0f) ? agent_cost - 0.5f : agent_cost + 0.5f;
       const float c1 = (obs_cost <= 0.0f) ? obs_cost - 0.5f : obs_cost + 0.5f;
-      reinterpret_cast<float2*>(a.cost)[(size_t)b * n + i] = make_float2(clampf(c0, -1.0f, 1.0f), clampf(c1, -1.0f, 1.0f));
+      reinterpret_cast<float2*>(a.cost)[(size_t)b * n + i] = make_float2(clampf_nan(c0, -1.0f, 1.0f), clampf_nan(c1, -1.0f, 1.0f));
     }
     if (tid >= GO && tid < GO + n) {
       const int g = tid - GO, base = n * n + n * k;
@@ -820,6 +768,16 @@ static size_t step_smem_bytes(const dgppo_env_cfg& c) {
   return fl * sizeof(float);
 }
 
+// smallest float s >= 0 whose correctly rounded square root is >= c: for s >= 0, fl(sqrt(s)) < c  <=>  s < sqrt_threshold(c)
+// (fl(sqrt) is monotone), so a radius mask can compare the squared distance and skip the root without changing a bit
+static float sqrt_threshold(float c) {
+  if (!(c > 0.0f)) return 0.0f;
+  float s = c * c;
+  while (s > 0.0f && sqrtf(s) >= c) s = nextafterf(s, 0.0f);
+  while (!(sqrtf(s) >= c)) s = nextafterf(s, INFINITY);
+  return s;
+}
+
 static int32_t launch_step(const dgppo_env_cfg* cfg, int mode, const float* agent, const float* action, const float* goal,
                            const float* obst, const float* hits, const float* ray_cos, const float* ray_sin,
                            float* next_agent, float* next_hits, float* reward, float* cost, const dgppo_graph_out* gout,
@@ -862,6 +820,8 @@ static int32_t launch_step(const dgppo_env_cfg* cfg, int mode, const float* agen
   a.B = B;
   a.rcp_n = fdiv_rcp(cfg->n_agents); a.rcp_k = fdiv_rcp(cfg->top_k); a.rcp_no = fdiv_rcp(cfg->n_obs);
   a.rcp_no4 = fdiv_rcp(4 * (cfg->n_obs > 0 ? cfg->n_obs : 1));
+  a.thr2_comm = sqrt_threshold(cfg->comm_radius);
+  a.thr2_lidar = sqrt_threshold(cfg->lidar_mask_radius);
   const size_t smem = step_smem_bytes(*cfg);
   DGPPO_REQUIRE(smem <= 64 * 1024, "env too large for the per-env LDS stage (%zu bytes)", smem);
   int work = cfg->n_agents * (lidar ? cfg->n_rays : 1);
@@ -872,7 +832,9 @@ static int32_t launch_step(const dgppo_env_cfg* cfg, int mode, const float* agen
   if (threads > 512) threads = 512;
   hipStream_t s = (hipStream_t)stream;
   const size_t fsmem = lidar ? lidar_smem_bytes(*cfg) : 0;
-  if (lidar && cfg->n_obs > 0 && cfg->n_rays == 32 && fsmem <= 60 * 1024 && !getenv("DGPPO_GENERIC_ENV_KERNEL")) {
+  if (launch_lidar_wave(a, s)) {
+    // wave-per-env kernel for the benchmark topologies (env_wave.hip; same outputs bit for bit)
+  } else if (lidar && cfg->n_obs > 0 && cfg->n_rays == 32 && fsmem <= 60 * 1024 && !getenv("DGPPO_GENERIC_ENV_KERNEL")) {
     // specialised LiDAR kernel (same outputs bit for bit; see its header)
     const bool spread = cfg_is_spread(*cfg);
     const char* nt_env = getenv("DGPPO_ENV_BLOCK");

@@ -1,0 +1,623 @@
+// Wave-per-environment LiDAR env.step for the benchmark topologies (n_rays = 32, top_k = 8, compile-time n_agents / n_obs):
+// the same outputs, bit for bit, as env_step_kernel / lidar_step_kernel in env_step.hip (and oracle/env_np.py), organised
+// around INSTRUCTION COUNT — at 4096+ envs per launch the workgroup-per-env kernel is VALU/SALU-issue bound
+// (profiles/README.md: 1 661 VALU + 891 SALU per wave, two waves per env).
+//
+// Reference arithmetic replaced: the same list as env_step.hip (LidarEnv.step dgppo/env/lidar_env/base.py:151-174 and
+// everything it calls: env/utils.py:49-55,115-136, obstacle.py:62-105, lidar_spread.py:35-96, lidar_target.py:35-96,
+// lidar_bicycle_target.py:92-118, lidar_env/base.py:180-271, utils/graph.py:35-44,212-247).
+//
+// What is different from lidar_step_kernel:
+//   * one WAVE owns one environment at a time and loops over environments (persistent waves, 4 independent waves per
+//     workgroup, each with its own LDS slab): no s_barrier anywhere — the phases of an env are ordered by the in-order
+//     execution of a wave's DS instructions, so a compiler barrier between phases is all that is needed;
+//   * every size is a template parameter: all loops unroll, index divisions fold, no dynamic-trip-count loop scaffolding;
+//   * the constant parts of the node / state rows (indicator columns, zero padding, the pad row) are written into the
+//     wave's LDS image ONCE; per env only agent / goal states and hit points are patched in, then the image is streamed out;
+//   * segment tests of an obstacle are SKIPPED for a pair of agents when both are provably out of its reach (see "cull");
+//   * stable top-k straight from registers: ranks of the (many) missing rays by popcount of ballots, ranks of the (few)
+//     hitting rays by a wave-uniform loop over the hitting lanes — no 32-key compare ladder, no keys in LDS;
+//   * per-agent minima (cost, goal distances) by DPP row reductions instead of serial LDS loops.
+//
+// Cull (rigorous, keeps bit-exactness).  For agent position p and obstacle o let c_o be the mean of the four vertices the
+// kernel actually uses and h_o the largest vertex distance from c_o.  If |p - c_o| > R + h_o + 0.05 (R = comm_radius =
+// ray length) then every point of every edge P_m + beta e_m, beta in [0,1], is farther than R + 0.049 from p.  The test
+// of obstacle.py:97-105 accepts a segment iff 0 <= na' <= |det| and 0 <= nb' <= |det| in fp32.  If additionally
+// |det| >= 1e-4 for every (ray, edge) of that obstacle (checked per env from the ray table and the edge vectors:
+// 0.5 |dir_r x e_m| >= 2e-4 for the two edge directions, the opposite edges differ by < 3e-7), then the accepted
+// (alpha, beta) are within 4e-3 of the exact intersection parameters of the two lines (numerator errors < 3e-7), i.e.
+// the exact intersection point would lie within 0.502 R of p and within 2e-3 of the edge — impossible at that distance.
+// So no segment of a culled obstacle can be valid for either agent of the pair, det cannot be 0 or NaN there (NaN inputs
+// fail the distance comparison and are never culled), and skipping the obstacle leaves alpha unchanged.  Obstacles whose
+// edges are nearly parallel to a ray of the fan (about 1 in 70) are simply never culled.
+#include "env_step.h"
+#include <stdlib.h>
+
+namespace {
+
+// compiler-level ordering between phases of one wave: DS instructions of a wave execute in issue order, so a later
+// ds_read observes an earlier ds_write of ANY lane of the same wave; only the compiler must not reorder them
+#define WSYNC() asm volatile("" ::: "memory")
+
+constexpr int ceil4(int x) { return (x + 3) / 4 * 4; }
+
+template <int SD, bool SPREAD, int NA, int NO>
+struct WC {
+  static constexpr int K = 8, R = 32, ND = SD + 3;
+  static constexpr int NR = NA * R, NIT = NR / 64;
+  static constexpr int NHIT = NA * K;
+  static constexpr int N = 2 * NA + NHIT + 1, PAD = N - 1;
+  static constexpr int GS = SPREAD ? NA : 1;
+  static constexpr int E = NA * (NA + GS + K);
+  static constexpr int NPAIR = NA * NO;
+  static constexpr int NFAR = (NPAIR + 63) / 64;
+  static_assert(NA % 2 == 0 && NA >= 2 && NA <= 16, "wave kernel: even n_agents <= 16 (two agents share a wave iteration)");
+  static_assert((NA & (NA - 1)) == 0 && NA >= 4, "wave kernel: n_agents must be a power of two >= 4 (DPP group reductions)");
+  static_assert(NO >= 1 && NO * 4 <= 64, "wave kernel: 1 <= n_obs <= 16");
+  static_assert((NA * SD) % 4 == 0, "agent / goal rows are staged as float4");
+};
+
+// per-wave LDS slab; every member is a multiple of 16 bytes so each starts 16-byte aligned
+template <int SD, bool SPREAD, int NA, int NO>
+struct alignas(16) WaveLds {
+  using C = WC<SD, SPREAD, NA, NO>;
+  float4 seg[NO * 4];                 // per segment: x3, y3, ex = x4 - x3, ey = y4 - y3
+  float4 as[NA * NO * 4];             // per (agent, segment): ax = x1 - x3, ay = y1 - y3, na = ey ax - ex ay
+  float4 circ[NO];                    // cull circle: cx, cy, (R + h + 0.05)^2
+  float next[ceil4(NA * SD)];         // state at t+1
+  float agent[ceil4(NA * SD)];        // state at t
+  float goal[ceil4(NA * SD)];
+  float act[ceil4(NA * 2)];           // clipped action
+  float obst[NO * 16];
+  float hpre[NA * C::K * 2];          // hit points of graph_t
+  float hnext[NA * C::K * 2];         // hit points of graph_{t+1}
+  float fa[NA * 4];                   // state2feat(next agent)
+  float fg[NA * 4];
+  float ino[ceil4(NA * NO)];          // start-inside flags
+  float red[ceil4(3 * NA)];           // reward terms: d2g | indicator | ||a||^2
+  float cost[ceil4(NA * 2)];
+  float sq[4 * NA];                   // squared minima awaiting ONE square root: agent-agent | agent-hit | goal-agent | ||a||^2
+  float states[ceil4(C::N * SD)];     // [N, SD] image
+  float nodes[ceil4(C::N * C::ND)];   // [N, ND] image
+};
+
+__device__ inline float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ inline float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// Rectangle.inside with r = 0 (obstacle.py:62-72 as called by env/utils.py:117): with r = 0 the corner-circle term
+// sqrt(.) < 0 is never true (also not for NaN), so the test reduces to both local coordinates being inside
+__device__ inline bool rect_inside_r0(const float* rec, float px, float py) {
+  const float rel_x = px - rec[0], rel_y = py - rec[1];
+  const float cs = rec[5], sn = rec[6];
+  const float rel_xx = fabsf(rel_x * cs + rel_y * sn) - rec[2] / 2.0f;
+  const float rel_yy = fabsf(rel_x * sn - rel_y * cs) - rec[3] / 2.0f;
+  return (rel_xx < 0.0f) && (rel_yy < 0.0f);
+}
+
+template <int CTRL>
+__device__ inline float dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_XOR1 = 0xB1;      // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;      // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// min over aligned groups of G lanes (G = 4, 8 or 16), jnp.min semantics (NaN propagates).  NaNs are practically
+// never present, so the wave takes the 1-instruction-per-step path unless some lane holds one.
+template <int G>
+__device__ inline float group_min(float x) {
+  if (__builtin_amdgcn_ballot_w64(x != x) == 0ull) {
+    x = raw_min(x, dpp<DPP_XOR1>(x));
+    x = raw_min(x, dpp<DPP_XOR2>(x));
+    if constexpr (G >= 8) x = raw_min(x, dpp<DPP_HALF_MIRROR>(x));
+    if constexpr (G >= 16) x = raw_min(x, dpp<DPP_ROW_MIRROR>(x));
+  } else {
+    x = nanmin(x, dpp<DPP_XOR1>(x));
+    x = nanmin(x, dpp<DPP_XOR2>(x));
+    if constexpr (G >= 8) x = nanmin(x, dpp<DPP_HALF_MIRROR>(x));
+    if constexpr (G >= 16) x = nanmin(x, dpp<DPP_ROW_MIRROR>(x));
+  }
+  return x;
+}
+
+template <int SD, bool SPREAD, int NA, int NO, int WPB>
+__global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
+  using C = WC<SD, SPREAD, NA, NO>;
+  using LT = WaveLds<SD, SPREAD, NA, NO>;
+  constexpr int K = C::K, ND = C::ND, N = C::N, PAD = C::PAD, NIT = C::NIT, GS = C::GS, E = C::E;
+  extern __shared__ float4 smem4[];
+  int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  LT& L = reinterpret_cast<LT*>(smem4)[wave];
+  const dgppo_env_cfg& c = a.cfg;
+  const bool do_dyn = (a.mode == MODE_STEP);
+  const bool do_sense = (a.mode != MODE_GRAPH);
+  const float sr = c.comm_radius;
+  const int r = lane & 31;                      // this lane's ray, for the whole kernel
+  const int hi_half = lane >> 5;                // which of the two agents of a wave iteration
+  const float cr = do_sense ? a.ray_cos[r] : 0.0f, sn = do_sense ? a.ray_sin[r] : 0.0f;
+  const uint32_t below = (1u << r) - 1u;        // lanes of my half with a smaller ray index
+
+  // ---- once per wave: the constant part of the node / state images (lidar_env/base.py:236-264, graph.py:214-218) ----
+  for (int i = lane; i < ceil4(N * ND); i += 64) L.nodes[i] = 0.0f;
+  for (int i = lane; i < ceil4(N * SD); i += 64) L.states[i] = 0.0f;
+  WSYNC();
+  for (int node = lane; node < N; node += 64) {
+    if (node < NA) L.nodes[node * ND + SD + 2] = 1.0f;
+    else if (node < 2 * NA) L.nodes[node * ND + SD + 1] = 1.0f;
+    else if (node < PAD) L.nodes[node * ND + SD] = 1.0f;
+    else {
+#pragma unroll
+      for (int d = 0; d < SD; ++d) L.states[node * SD + d] = -1.0f;   // pad row, graph.py:217
+    }
+  }
+  WSYNC();
+
+  for (int b = blockIdx.x * WPB + wave; b < a.B; b += gridDim.x * WPB) {
+    // make the lane id opaque per environment: otherwise every lane-dependent LDS / global address of the (fully
+    // unrolled) body is hoisted out of this loop and kept live — ~170 VGPRs, 3 waves per SIMD; recomputing them costs a
+    // few dozen VALU instructions per env and keeps the kernel under 128
+    asm volatile("" : "+v"(lane));
+    // ---- P0: stage the env's inputs (16-byte loads; the per-env blocks are 16-byte aligned for these sizes) ----
+    {
+      const float4* ag4 = reinterpret_cast<const float4*>(a.agent + (size_t)b * NA * SD);
+      const float4* go4 = reinterpret_cast<const float4*>(a.goal + (size_t)b * NA * SD);
+      for (int i = lane; i < NA * SD / 4; i += 64) {
+        reinterpret_cast<float4*>(L.agent)[i] = ag4[i];
+        reinterpret_cast<float4*>(L.goal)[i] = go4[i];
+      }
+      if (do_dyn) {
+        const float2* ac2 = reinterpret_cast<const float2*>(a.action + (size_t)b * NA * 2);
+        for (int i = lane; i < NA; i += 64) {
+          const float2 u = ac2[i];
+          reinterpret_cast<float2*>(L.act)[i] = make_float2(clampf(u.x, -1.0f, 1.0f), clampf(u.y, -1.0f, 1.0f));  // env/base.py:84-86
+        }
+      }
+      const float4* ob4 = reinterpret_cast<const float4*>(a.obst + (size_t)b * NO * 16);
+      for (int i = lane; i < NO * 4; i += 64) reinterpret_cast<float4*>(L.obst)[i] = ob4[i];
+      if (a.hits != nullptr) {
+        const float4* hp4 = reinterpret_cast<const float4*>(a.hits + (size_t)b * NA * K * 2);
+        for (int i = lane; i < NA * K * 2 / 4; i += 64) reinterpret_cast<float4*>(L.hpre)[i] = hp4[i];
+      }
+    }
+    WSYNC();
+    // ---- P1a: dynamics + features (lanes < NA), goal features (lanes 32..), segment constants, cull circles ----
+    if (lane < NA) {
+      const int i = lane;
+      const float* x = L.agent + i * SD;
+      float nx[SD];
+      if (do_dyn) {
+        const float u0 = L.act[i * 2], u1 = L.act[i * 2 + 1];
+        const float dt = c.dt, A = c.area_size;
+        if constexpr (SD == 5) {  // lidar_bicycle_target.py:95-107
+          const float theta = atan2f(x[3], x[2]);
+          const float theta_next = theta + x[4] * u0 * dt * 10.0f;
+          nx[0] = clampf(x[0] + x[4] * cosf(theta) * dt, 0.0f, A);
+          nx[1] = clampf(x[1] + x[4] * sinf(theta) * dt, 0.0f, A);
+          nx[2] = clampf(cosf(theta_next), -1.0f, 1.0f);
+          nx[3] = clampf(sinf(theta_next), -1.0f, 1.0f);
+          nx[SD - 1] = clampf(x[SD - 1] + u1 * dt * 10.0f, -0.5f, 0.5f);
+        } else {                  // lidar_env/base.py:146-149
+          const float vl = c.vel_limit;
+          nx[0] = clampf(x[2] * dt + x[0], 0.0f, A);
+          nx[1] = clampf(x[3] * dt + x[1], 0.0f, A);
+          nx[2] = clampf((u0 * 10.0f) * dt + x[2], -vl, vl);
+          nx[3] = clampf((u1 * 10.0f) * dt + x[3], -vl, vl);
+        }
+        L.sq[3 * NA + i] = u0 * u0 + u1 * u1;     // (||a||)^2 = fl(sqrt(.))^2: the root is taken below with the distances
+      } else {
+#pragma unroll
+        for (int d = 0; d < SD; ++d) nx[d] = x[d];
+      }
+#pragma unroll
+      for (int d = 0; d < SD; ++d) L.next[i * SD + d] = nx[d];
+      state2feat<SD>(nx, L.fa + i * 4);
+    }
+    if (lane >= 32 && lane < 32 + NA) state2feat<SD>(L.goal + (lane - 32) * SD, L.fg + (lane - 32) * 4);
+    uint32_t robust_bits = 0;                      // bit o: every (ray, edge) determinant of obstacle o is >= 1e-4 in magnitude
+    if (do_sense) {
+      if (lane < NO * 4) {
+        const int o = lane >> 2, m = lane & 3, mm = (m + 3) & 3;
+        const float* P = L.obst + o * 16 + 8;
+        L.seg[lane] = make_float4(P[2 * m], P[2 * m + 1], P[2 * mm] - P[2 * m], P[2 * mm + 1] - P[2 * m + 1]);
+      }
+      if (lane < NO) {
+        const float* P = L.obst + lane * 16 + 8;
+        const float cx = ((P[0] + P[2]) + (P[4] + P[6])) * 0.25f, cy = ((P[1] + P[3]) + (P[5] + P[7])) * 0.25f;
+        float h2 = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float dx = P[2 * m] - cx, dy = P[2 * m + 1] - cy;
+          h2 = fmaxf(h2, dx * dx + dy * dy);
+        }
+        const float thr = sr + sqrtf(h2) + 0.05f;
+        L.circ[lane] = make_float4(cx, cy, thr * thr, 0.0f);
+      }
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {               // lanes: edge direction m = lane >> 5 (0, 1), ray = lane & 31
+        const int m = hi_half, mm = (m + 3) & 3;
+        const float* P = L.obst + o * 16 + 8;
+        const float ex = P[2 * mm] - P[2 * m], ey = P[2 * mm + 1] - P[2 * m + 1];
+        const float cc = cr * ey - sn * ex;
+        const bool weak = !(fabsf(cc) >= 4e-4f);   // also true for NaN
+        if (__builtin_amdgcn_ballot_w64(weak) == 0ull) robust_bits |= (1u << o);
+      }
+    }
+    WSYNC();
+    // ---- P1b: (agent, obstacle) start-inside flags + cull bits, (agent, segment) terms, pre-step distances ----
+    uint64_t far[C::NFAR];
+    if (do_sense) {
+#pragma unroll
+      for (int w = 0; w < C::NFAR; ++w) {
+        const int q = w * 64 + lane;
+        bool isfar = false;
+        if (q < C::NPAIR) {
+          const int i = q / NO, o = q - i * NO;
+          const float px = L.next[i * SD], py = L.next[i * SD + 1];
+          L.ino[q] = rect_inside_r0(L.obst + o * 16, px, py) ? 1.0f : 0.0f;
+          const float4 cc = L.circ[o];
+          const float dx = px - cc.x, dy = py - cc.y;
+          isfar = (dx * dx + dy * dy > cc.z) && ((robust_bits >> o) & 1u);
+        }
+        far[w] = __builtin_amdgcn_ballot_w64(isfar);
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < NA * NO * 4; q0 += 64) {   // ray-independent part of the segment test
+        const int q = q0 + lane;
+        if (q < NA * NO * 4) {
+          const int i = q / (NO * 4), sgi = q - i * (NO * 4);
+          const float4 sg = L.seg[sgi];
+          const float ax = L.next[i * SD] - sg.x, ay = L.next[i * SD + 1] - sg.y;
+          L.as[q] = make_float4(ax, ay, sg.w * ax - sg.z * ay, 0.0f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int w = 0; w < C::NFAR; ++w) far[w] = 0ull;
+    }
+    if (do_dyn) {  // cost and reward terms on the PRE-step graph (lidar_env/base.py:170-171,180-207; lidar_spread.py:35-52)
+      // The reference takes min_j sqrt(s_j); the correctly rounded square root is monotone, so min_j fl(sqrt(s_j)) ==
+      // fl(sqrt(min_j s_j)) bit for bit: reduce the SQUARED distances and take one root per agent afterwards (the root is
+      // ~14 instructions per wave whatever the number of active lanes).
+#pragma unroll
+      for (int q0 = 0; q0 < NA * NA; q0 += 64) {    // agent-agent: min over j != i of ||p_i - p_j||^2 (the diagonal's
+        const int q = q0 + lane, i = q / NA, j = q - i * NA;   // sqrt(0) + 1e6 enters after the root)
+        float d = __builtin_inff();
+        if (q < NA * NA && j != i) {
+          const float dx = L.agent[i * SD] - L.agent[j * SD], dy = L.agent[i * SD + 1] - L.agent[j * SD + 1];
+          d = dx * dx + dy * dy;
+        }
+        const float md2 = group_min<NA>(d);
+        if (q < NA * NA && j == 0) L.sq[i] = md2;
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < NA * K; q0 += 64) {     // agent-hit: min over the agent's k hit points of graph_t
+        const int q = q0 + lane, i = q / K;
+        float d = __builtin_inff();
+        if (q < NA * K) {
+          const float dx = L.hpre[q * 2] - L.agent[i * SD], dy = L.hpre[q * 2 + 1] - L.agent[i * SD + 1];
+          d = dx * dx + dy * dy;
+        }
+        const float mo2 = group_min<K>(d);
+        if (q < NA * K && (q & (K - 1)) == 0) L.sq[NA + i] = mo2;
+      }
+      if constexpr (SPREAD) {                        // each goal: distance to the nearest agent
+#pragma unroll
+        for (int q0 = 0; q0 < NA * NA; q0 += 64) {
+          const int q = q0 + lane, g = q / NA, j = q - g * NA;
+          float d = __builtin_inff();
+          if (q < NA * NA) {
+            const float dx = L.goal[g * SD] - L.agent[j * SD], dy = L.goal[g * SD + 1] - L.agent[j * SD + 1];
+            d = dx * dx + dy * dy;
+          }
+          const float g2 = group_min<NA>(d);
+          if (q < NA * NA && j == 0) L.sq[2 * NA + g] = g2;
+        }
+      } else {                                       // paired goal
+        if (lane < NA) {
+          const int g = lane;
+          const float dx = L.goal[g * SD] - L.agent[g * SD], dy = L.goal[g * SD + 1] - L.agent[g * SD + 1];
+          L.sq[2 * NA + g] = dx * dx + dy * dy;
+        }
+      }
+      WSYNC();
+      static_assert(4 * NA <= 64, "one lane per pending square root");
+      if (lane < 4 * NA) {
+        const float rt = sqrtf(L.sq[lane]);          // the only square root of this phase
+        const int kind = lane / NA, i = lane - kind * NA;
+        if (kind == 0) {        // agent_cost = 2r - min(min_{j != i} dist, sqrt(0) + 1e6)   [jnp.min: NaN propagates]
+          const float md = nanmin(rt, 1e6f);
+          const float agent_cost = c.two_car_radius - md;
+          const float c0 = (agent_cost <= 0.0f) ? agent_cost - 0.5f : agent_cost + 0.5f;
+          L.cost[i * 2] = clampf_nan(c0, -1.0f, 1.0f);
+        } else if (kind == 1) {
+          const float obs_cost = c.car_radius - rt;
+          const float c1 = (obs_cost <= 0.0f) ? obs_cost - 0.5f : obs_cost + 0.5f;
+          L.cost[i * 2 + 1] = clampf_nan(c1, -1.0f, 1.0f);
+        } else if (kind == 2) {
+          L.red[i] = rt;
+          L.red[NA + i] = (rt > c.dist2goal) ? 1.0f : 0.0f;
+        } else {
+          L.red[2 * NA + i] = rt * rt;
+        }
+      }
+    }
+    WSYNC();
+    if (do_dyn) {
+      // reward: three sequential sums in index order (the oracle's seq_sum), one per lane, then combined on lane 0
+      float s = 0.0f;
+      if (lane < 3) {
+        s = L.red[lane * NA];
+#pragma unroll
+        for (int g = 1; g < NA; ++g) s = s + L.red[lane * NA + g];
+      }
+      const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
+      const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 1));
+      const float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 2));
+      if (lane == 0) {
+        float rw = 0.0f;
+        rw = rw - (s1 / (float)NA) * 0.01f;
+        rw = rw - (s2 / (float)NA) * 0.001f;
+        rw = rw - (s3 / (float)NA) * 0.0001f;
+        a.reward[b] = rw;
+      }
+      if (lane < NA * 2) a.cost[(size_t)b * NA * 2 + lane] = L.cost[lane];
+    }
+    // ---- P2 + P3: per wave iteration, two agents x 32 rays: segment tests (obstacle.py:97-105) -> alpha -> stable
+    //      top-k (env/utils.py:132-136) -> hit points patched into hnext and the node / state images ----
+    if (do_sense) {
+#pragma unroll(NIT <= 4 ? NIT : 1)
+      for (int it = 0; it < NIT; ++it) {
+        const int i = it * 2 + hi_half;
+        const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
+        const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
+        const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
+        float amin = 1e6f, is_in = 0.0f;
+        bool bad = false;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) is_in = fmaxf(is_in, L.ino[i * NO + o]);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          const int qa = (it * 2) * NO + o, qb = (it * 2 + 1) * NO + o;
+          const bool fa_ = (far[qa >> 6] >> (qa & 63)) & 1ull, fb_ = (far[qb >> 6] >> (qb & 63)) & 1ull;
+          if (fa_ && fb_) continue;                  // wave-uniform: neither agent of this iteration can reach obstacle o
+          float4 sg[4], as[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { sg[m] = L.seg[o * 4 + m]; as[m] = L.as[(i * NO + o) * 4 + m]; }
+          float naf[4], adet[4];
+          bool valid[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float det0 = dx12 * sg[m].w - dy12 * sg[m].z;
+            const float nb = ndy12 * as[m].x + dx12 * as[m].y;
+            // flip both numerators by the sign of det: (na/det, nb/det) == (na'/|det|, nb'/|det|), exactly
+            const uint32_t sb = __float_as_uint(det0) & 0x80000000u;
+            naf[m] = __uint_as_float(__float_as_uint(as[m].z) ^ sb);
+            const float nbf = __uint_as_float(__float_as_uint(nb) ^ sb);
+            adet[m] = __builtin_amdgcn_fmed3f(fabsf(det0), 1e-7f, 1e7f);      // clip(|det|, 1e-7, 1e7)
+            const float mn = raw_min(naf[m], nbf), mx = raw_max(naf[m], nbf);
+            // 0 <= q <= 1 for both quotients  <=>  0 <= min(na', nb') and max(na', nb') <= |det|   (-0 >= 0 holds, like -0/d >= 0)
+            valid[m] = (mn >= 0.0f) && (mx <= adet[m]);
+            bad = bad || !(det0 != 0.0f);                                      // zero or NaN
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            if (__builtin_amdgcn_ballot_w64(valid[m]) != 0ull) {              // wave-uniform: skip the division when no lane hits
+              const float qa_ = naf[m] / adet[m] + 0.0f;                      // v*alpha + (1-v)*1e6 with v = 1 (turns -0 into +0)
+              const float al = valid[m] ? qa_ : 1e6f;
+              amin = raw_min(amin, al);
+            }
+          }
+        }
+        float ar = amin;
+        if (bad) {                         // literal reference arithmetic for every segment of this lane (see lidar_step_kernel)
+          float lmin = 1e6f;
+          bool any_nan = false;
+          for (int q = 0; q < NO * 4; ++q) {
+            const float4 sgq = L.seg[q];
+            const float4 asq = L.as[i * NO * 4 + q];
+            const float det0 = dx12 * sgq.w - dy12 * sgq.z;
+            const float nb = ndy12 * asq.x + dx12 * asq.y;
+            const float sgn = (det0 > 0.0f) ? 1.0f : ((det0 < 0.0f) ? -1.0f : det0);
+            const float dz = sgn * fminf(fmaxf(fabsf(det0), 1e-7f), 1e7f);
+            const float aq = asq.z / dz, bq = nb / dz;
+            const float v = ((aq <= 1.0f) && (aq >= 0.0f) && (bq <= 1.0f) && (bq >= 0.0f)) ? 1.0f : 0.0f;
+            const float al = v * aq + (1.0f - v) * 1e6f;
+            any_nan = any_nan || (al != al);
+            lmin = fminf(lmin, al);
+          }
+          ar = any_nan ? __builtin_nanf("") : lmin;
+        }
+        ar = ar * (1.0f - is_in);
+        // sort key: float bits (alphas are >= +0), NaN -> max.  Classes: L (hit, key < 1e6), M (miss, key == 1e6), H (NaN)
+        const uint32_t kr = (ar != ar) ? 0xFFFFFFFFu : __float_as_uint(ar);
+        const uint64_t Lm = __builtin_amdgcn_ballot_w64(kr < MISS_BITS);
+        const uint64_t Mm = __builtin_amdgcn_ballot_w64(kr == MISS_BITS);
+        const uint64_t Zm = __builtin_amdgcn_ballot_w64(kr == 0u);
+        uint32_t lo = (uint32_t)Lm, hi = (uint32_t)(Lm >> 32);
+        const uint32_t myL = hi_half ? hi : lo;
+        const uint32_t myM = hi_half ? (uint32_t)(Mm >> 32) : (uint32_t)Mm;
+        const int cntL = __popc(myL);
+        // misses keep ray order behind all hits; NaNs behind the misses (stable ascending sort)
+        const int rank_other = (kr == MISS_BITS) ? cntL + __popc(myM & below)
+                                                 : cntL + __popc(myM) + __popc(~(myL | myM) & below);
+        // an agent that starts inside an obstacle has all 32 alphas == 0: ranks are the ray indices
+        const bool z_lo = ((uint32_t)Zm == 0xFFFFFFFFu), z_hi = ((uint32_t)(Zm >> 32) == 0xFFFFFFFFu);
+        if (z_lo) lo = 0u;
+        if (z_hi) hi = 0u;
+        int rankL = 0;
+        while ((lo | hi) != 0u) {          // wave-uniform loop over the hitting lanes, one of each half per trip
+          const int jl = lo ? __builtin_ctz(lo) : 0, jh = hi ? __builtin_ctz(hi) : 0;
+          const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)kr, jl);
+          const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)kr, 32 + jh);
+          const bool vl = (lo != 0u), vh = (hi != 0u);
+          const uint32_t kj = hi_half ? kh : kl;
+          const int jj = hi_half ? jh : jl;
+          const bool vj = hi_half ? vh : vl;
+          rankL += (vj && (kj < kr || (kj == kr && jj < r))) ? 1 : 0;
+          lo &= lo - 1u;
+          hi &= hi - 1u;
+        }
+        const bool allz = hi_half ? z_hi : z_lo;
+        const int rank = allz ? r : ((kr < MISS_BITS) ? rankL : rank_other);
+        if (rank < K) {
+          const float hx = x1 + (x2 - x1) * ar, hy = y1 + (y2 - y1) * ar;
+          const int hq = i * K + rank, node = 2 * NA + hq;
+          L.hnext[hq * 2] = hx; L.hnext[hq * 2 + 1] = hy;
+          L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
+          L.states[node * SD] = hx; L.states[node * SD + 1] = hy;
+        }
+      }
+    } else {
+      // materialise-only: the hit points are given
+      for (int q = lane; q < NA * K; q += 64) {
+        const float hx = L.hpre[q * 2], hy = L.hpre[q * 2 + 1];
+        const int node = 2 * NA + q;
+        L.hnext[q * 2] = hx; L.hnext[q * 2 + 1] = hy;
+        L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
+        L.states[node * SD] = hx; L.states[node * SD + 1] = hy;
+      }
+    }
+    if (a.has_graph) {                     // agent / goal rows of the images
+      for (int q = lane; q < NA * SD; q += 64) {
+        const int node = q / SD, d = q - node * SD;
+        const float va = L.next[q], vg = L.goal[q];
+        L.nodes[node * ND + d] = va; L.states[q] = va;
+        L.nodes[(NA + node) * ND + d] = vg; L.states[NA * SD + q] = vg;
+      }
+    }
+    WSYNC();
+    // ---- P4: compact outputs ----
+    if (a.next_agent != nullptr) {
+      float4* o4 = reinterpret_cast<float4*>(a.next_agent + (size_t)b * NA * SD);
+      for (int i = lane; i < NA * SD / 4; i += 64) o4[i] = reinterpret_cast<const float4*>(L.next)[i];
+    }
+    if (a.next_hits != nullptr) {
+      float4* o4 = reinterpret_cast<float4*>(a.next_hits + (size_t)b * NA * K * 2);
+      for (int i = lane; i < NA * K * 2 / 4; i += 64) o4[i] = reinterpret_cast<const float4*>(L.hnext)[i];
+    }
+    if (!a.has_graph) continue;
+    // ---- P5: padded GraphsTuple (lidar_env/base.py:227-271, lidar_spread.py:57-96, lidar_target.py:57-96, graph.py:35-44,212-247)
+    {
+      float4* edges = reinterpret_cast<float4*>(a.g.edges) + (size_t)b * E;
+      int32_t* recv = a.g.receivers + (size_t)b * E;
+      int32_t* send = a.g.senders + (size_t)b * E;
+#pragma unroll
+      for (int q0 = 0; q0 < NA * NA; q0 += 64) {     // agent-agent block
+        const int q = q0 + lane;
+        if (q < NA * NA) {
+          const int i = q / NA, j = q - i * NA;
+          const float4 fi = reinterpret_cast<const float4*>(L.fa)[i], fj = reinterpret_cast<const float4*>(L.fa)[j];
+          const float dx = L.next[i * SD] - L.next[j * SD], dy = L.next[i * SD + 1] - L.next[j * SD + 1];
+          // (sqrt(s) + (i == j ? comm_radius + 1 : 0)) < comm_radius  <=>  i != j && s < T, T = the smallest float whose
+          // correctly rounded root reaches comm_radius (host-computed, sqrt_threshold()); false for NaN on both sides
+          const bool mask = (i != j) && (dx * dx + dy * dy < a.thr2_comm);
+          edges[q] = make_float4(fi.x - fj.x, fi.y - fj.y, fi.z - fj.z, fi.w - fj.w);
+          recv[q] = mask ? i : PAD;
+          send[q] = mask ? j : PAD;
+        }
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < NA * GS; q0 += 64) {     // agent-goal block (all-true mask)
+        const int q = q0 + lane;
+        if (q < NA * GS) {
+          const int i = SPREAD ? q / NA : q, g = SPREAD ? q - i * NA : q;
+          const float4 fi = reinterpret_cast<const float4*>(L.fa)[i], fg = reinterpret_cast<const float4*>(L.fg)[g];
+          edges[NA * NA + q] = make_float4(fi.x - fg.x, fi.y - fg.y, fi.z - fg.z, fi.w - fg.w);
+          recv[NA * NA + q] = i;
+          send[NA * NA + q] = NA + g;
+        }
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < NA * K; q0 += 64) {      // agent-hit block
+        const int q = q0 + lane;
+        if (q < NA * K) {
+          const int i = q / K;
+          const float lx = L.next[i * SD] - L.hnext[q * 2], ly = L.next[i * SD + 1] - L.hnext[q * 2 + 1];
+          const bool mask = lx * lx + ly * ly < a.thr2_lidar;      // sqrt(s) < comm_radius - 0.1, as above
+          edges[NA * NA + NA * GS + q] = make_float4(lx, ly, 0.0f, 0.0f);
+          recv[NA * NA + NA * GS + q] = mask ? i : PAD;
+          send[NA * NA + NA * GS + q] = mask ? 2 * NA + q : PAD;
+        }
+      }
+      int32_t* nty = a.g.node_type + (size_t)b * N;
+#pragma unroll
+      for (int q0 = 0; q0 < N; q0 += 64) {
+        const int node = q0 + lane;
+        if (node < N) nty[node] = (node < NA) ? 0 : ((node < 2 * NA) ? 1 : ((node < PAD) ? 2 : -1));
+      }
+      if (lane == 0) { a.g.n_node[b] = N; a.g.n_edge[b] = E; }
+      float* nodes = a.g.nodes + (size_t)b * N * ND;
+#pragma unroll
+      for (int q0 = 0; q0 < N * ND; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < N * ND) nodes[q] = L.nodes[q];
+      }
+      if constexpr ((N * SD) % 4 == 0) {
+        float4* st4 = reinterpret_cast<float4*>(a.g.states + (size_t)b * N * SD);
+#pragma unroll
+        for (int q0 = 0; q0 < N * SD / 4; q0 += 64) {
+          const int q = q0 + lane;
+          if (q < N * SD / 4) st4[q] = reinterpret_cast<const float4*>(L.states)[q];
+        }
+      } else {
+        float* st = a.g.states + (size_t)b * N * SD;
+#pragma unroll
+        for (int q0 = 0; q0 < N * SD; q0 += 64) {
+          const int q = q0 + lane;
+          if (q < N * SD) st[q] = L.states[q];
+        }
+      }
+    }
+    WSYNC();   // the next env patches the images only after this env's reads of them were issued
+  }
+}
+
+template <int SD, bool SPREAD, int NA, int NO>
+bool launch_inst(const StepArgs& a, hipStream_t s) {
+  using LT = WaveLds<SD, SPREAD, NA, NO>;
+  constexpr size_t per_wave = sizeof(LT);
+  // waves per workgroup: as many independent waves as keep several workgroups resident in the 160 KiB of a CU
+  constexpr int WPB = (per_wave * 4 <= 40 * 1024) ? 4 : ((per_wave * 2 <= 52 * 1024) ? 2 : 1);
+  static_assert(per_wave * WPB <= 64 * 1024, "LDS slab too large");
+  constexpr size_t smem = per_wave * WPB;
+  const int per_cu = (int)((160 * 1024) / smem) < (32 / WPB) ? (int)((160 * 1024) / smem) : (32 / WPB);
+  const int max_blocks = 256 * (per_cu > 0 ? per_cu : 1);
+  int blocks = (a.B + WPB - 1) / WPB;
+  if (blocks > max_blocks) blocks = max_blocks;
+  const char* wpe = getenv("DGPPO_WAVE_ENVS");    // tuning knob: minimum envs per wave (fewer, longer-lived waves)
+  if (wpe && atoi(wpe) > 1) {
+    const int want = (a.B + WPB * atoi(wpe) - 1) / (WPB * atoi(wpe));
+    if (want >= 1 && want < blocks) blocks = want;
+  }
+  hipLaunchKernelGGL((lidar_wave_kernel<SD, SPREAD, NA, NO, WPB>), dim3(blocks), dim3(WPB * 64), smem, s, a);
+  return true;
+}
+
+}  // namespace
+
+bool launch_lidar_wave(const StepArgs& a, hipStream_t s) {
+  const dgppo_env_cfg& c = a.cfg;
+  if (!cfg_is_lidar(c) || c.n_rays != 32 || c.top_k != 8 || c.n_obs < 1) return false;
+  if (getenv("DGPPO_NO_WAVE_ENV_KERNEL")) return false;
+  if (!(c.eye_offset >= c.comm_radius)) return false;          // the diagonal of the agent-agent block must be masked
+  // 16-byte staging loads need 16-byte aligned bases (torch allocations are; sliced views may not be)
+  auto al16 = [](const void* p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; };
+  if (!(al16(a.agent) && al16(a.goal) && al16(a.obst) && al16(a.hits) && al16(a.next_agent) && al16(a.next_hits) &&
+        al16(a.action)))
+    return false;
+  if (a.has_graph && !(al16(a.g.edges) && al16(a.g.states))) return false;
+  const bool spread = cfg_is_spread(c);
+  const int n = c.n_agents, no = c.n_obs, sd = c.state_dim;
+#define TRY(SD_, SP_, NA_, NO_) if (sd == SD_ && spread == SP_ && n == NA_ && no == NO_) return launch_inst<SD_, SP_, NA_, NO_>(a, s)
+  TRY(4, true, 8, 3);      // BASELINE configs 3 / 4: LidarSpread n = 8, obs = 3
+  TRY(4, false, 8, 3);     // LidarTarget n = 8, obs = 3
+  TRY(5, false, 16, 8);    // BASELINE config 5: LidarBicycleTarget n = 16, obs = 8
+  TRY(4, true, 16, 8);
+  TRY(4, true, 4, 2);
+  TRY(4, false, 4, 2);
+  TRY(5, false, 4, 3);
+#undef TRY
+  return false;
+}

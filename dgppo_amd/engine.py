@@ -88,7 +88,7 @@ class OptState:
     def __init__(self, n: int, device):
         self.m = torch.zeros(n, device=device)
         self.v = torch.zeros(n, device=device)
-        self.state = torch.zeros(8, device=device)
+        self.state = torch.zeros(N.OPT_STATE_FLOATS, device=device)
 
 
 class Engine:
@@ -497,7 +497,7 @@ class Engine:
         s = self.stats.cpu().numpy().copy()
         s[:3] /= self.world                                   # rows 0..2 were summed over the ranks with the gradients
         G, R, nh, B = L["G"], L["R"], L["nh"], L["B"]
-        o = {k: self.opt[k].state.cpu().numpy() for k in self.opt}
+        o = {k: self.opt[k].state[:8].cpu().numpy() for k in self.opt}
         pol_loss = s[2, 0] / R - self.hp.coef_ent * s[2, 1] / R
         out = {
             "Vl/loss": float(s[0, 0] / G), "Vl/grad_norm": float(o["Vl"][4]), "Vl/has_nan": float(o["Vl"][5]),

@@ -57,7 +57,7 @@ def clip_adam_step(params, grads, m, v, state, lr, max_norm, b1=0.9, b2=0.999, e
     n = params.numel()
     for t, nm in ((grads, "grads"), (m, "m"), (v, "v")):
         N.expect_shape(t, (n,), nm)
-    N.expect_shape(state, (8,), "state")
+    N.expect_shape(state, (N.OPT_STATE_FLOATS,), "state")
     rc = N.lib().dgppo_clip_adam_step(N.ptr(params), N.ptr(grads), N.ptr(m), N.ptr(v), C.c_int64(n), N.ptr(state),
                                       C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(max_norm),
                                       C.c_float(grad_scale), N.stream_ptr())

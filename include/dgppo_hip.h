@@ -247,11 +247,15 @@ int32_t dgppo_advantage(const float* Ql, const float* Vl, const float* Vh, float
 int32_t dgppo_shaped_reward(const float* reward, const float* cost, float cost_weight, float* out, int64_t rows,
                             int32_t n, int32_t nh, void* stream);
 /* compute_norm_and_clip + has_any_nan_or_inf (dgppo/trainer/utils.py:89-118) and optax.apply_if_finite(adam)
- * (dgppo/algo/informarl.py:131-137) on one flat buffer.  state [8] lives on the device:
- * [0..1] scratch, [2] adam count, [3] total steps, [4] last grad norm, [5] last non-finite flag.
+ * (dgppo/algo/informarl.py:131-137) on one flat buffer.  state [DGPPO_OPT_STATE_FLOATS] lives on the device (zero it once):
+ * [2] adam count, [3] total steps, [4] last grad norm, [5] last non-finite flag, [8..] per-workgroup partial sums of the
+ * norm / non-finite statistics — reduced in a FIXED order with no atomics, so that data-parallel replicas that start
+ * from identical gradients stay bit-identical.
  * grad_scale multiplies every gradient entry as it is read (norm, non-finite test and update all see g * grad_scale):
  * 1 for a single device, 1/world after dgppo_comm_allreduce_sum_f32 (the mean of equal-sized shards' gradients is the
  * gradient of the global mean loss), so the data-parallel path needs no separate scaling pass.                       */
+#define DGPPO_OPT_PARTIALS 256
+#define DGPPO_OPT_STATE_FLOATS (8 + 2 * DGPPO_OPT_PARTIALS)
 int32_t dgppo_clip_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, float* state, float lr,
                              float b1, float b2, float eps, float max_norm, float grad_scale, void* stream);
 

@@ -56,7 +56,9 @@ def test_clip_adam_matches_optax_semantics(cuda):
     n = 62660
     p = r.normal(size=n).astype(np.float32)
     pd = torch.from_numpy(p.copy()).to(cuda)
-    m = torch.zeros(n, device=cuda); v = torch.zeros(n, device=cuda); st = torch.zeros(8, device=cuda)
+    m = torch.zeros(n, device=cuda); v = torch.zeros(n, device=cuda)
+    from dgppo_amd import _native as N
+    st = torch.zeros(N.OPT_STATE_FLOATS, device=cuda)
     pr, mr, vr, cr = p.astype(np.float64), np.zeros(n), np.zeros(n), 0
     for k in range(4):
         g = (r.normal(size=n) * (0.001 if k == 1 else 0.05)).astype(np.float32)     # k=1: below max_norm -> no clipping

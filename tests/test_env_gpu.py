@@ -13,6 +13,8 @@ f32 = np.float32
 CASES = [
     ("LidarSpread", 8, 3), ("LidarSpread", 3, 1), ("LidarTarget", 4, 2), ("LidarSpread", 2, 0),
     ("MPESpread", 3, 3), ("MPETarget", 3, 0), ("MPETarget", 3, 3), ("MPESpread", 5, 2),
+    # the remaining instantiations of the wave-per-env kernel (csrc/env_wave.hip)
+    ("LidarTarget", 8, 3), ("LidarSpread", 4, 2), ("LidarSpread", 16, 8),
 ]
 
 
@@ -242,3 +244,70 @@ def test_generic_kernel_path_matches_specialised(cuda, monkeypatch):
     np.testing.assert_array_equal(nh.cpu().numpy().view(np.uint32), want["next_hits"].view(np.uint32))
     np.testing.assert_array_equal(cost.cpu().numpy().view(np.uint32), want["cost"].view(np.uint32))
     _assert_graph_equal({k: v.cpu().numpy() for k, v in g.items()}, want["graph"])
+
+
+def _adversarial_state(ocfg, B, seed):
+    """_random_state plus the corner cases of the ray-cast / top-k: agents INSIDE an obstacle (all 32 alphas are 0: ranks
+    are the ray indices), agents far from everything (every obstacle culled), two agents on the same spot, agents on the
+    area boundary, and a NaN hit point in the pre-step graph (the obstacle cost must come out NaN, like jnp.min)."""
+    agent, goal, obst, action = _random_state(ocfg, B, seed)
+    n = ocfg.n_agents
+    c = obst[:, :, 0:2]
+    for e in range(0, B, 7):
+        agent[e, e % n, :2] = c[e, e % ocfg.n_obs]                     # inside obstacle (its centre)
+        agent[e, e % n, 2:4] = 0.0
+    for e in range(1, B, 7):
+        agent[e, :, :2] = np.float32(1.49)                             # all agents piled in a corner, far from most obstacles
+    for e in range(2, B, 7):
+        agent[e, 1, :2] = agent[e, 0, :2]                              # coincident agents (distance exactly 0)
+    for e in range(3, B, 7):
+        agent[e, 0, :2] = 0.0                                          # on the boundary
+    return agent, goal, obst, action
+
+
+@pytest.mark.parametrize("kind,n,n_obs,B", [("LidarSpread", 8, 3, 1500), ("LidarTarget", 8, 3, 300),
+                                            ("LidarBicycleTarget", 16, 8, 200), ("LidarSpread", 4, 2, 333)])
+def test_wave_kernel_equals_workgroup_kernel_and_oracle(cuda, monkeypatch, kind, n, n_obs, B):
+    """csrc/env_wave.hip (wave-per-env, obstacle culling, ballot top-k, squared-distance minima and masks) against the
+    workgroup-per-env kernel of env_step.hip (forced with DGPPO_NO_WAVE_ENV_KERNEL) — every output, every bit, in all three
+    modes (step / sense-only / materialise), with persistent waves looping over several envs — and against the oracle."""
+    cfg, ocfg = _mk(kind, n, n_obs)
+    agent, goal, obst, action = _adversarial_state(ocfg, B, seed=5)
+    tab = E.ray_table(32)
+    hits, _ = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)
+    hits = hits.copy()
+    hits[5, 0, 3, 0] = np.nan                                           # a NaN hit point in graph_t
+    for wave_envs in ("1", "3"):
+        monkeypatch.setenv("DGPPO_WAVE_ENVS", wave_envs)                # 3: every wave walks >= 3 environments
+        fast = _run_step(cfg, ocfg, agent, goal, obst, hits, action, cuda)
+        fast_sense = _run_step(cfg, ocfg, agent, goal, obst, None, None, cuda)
+        monkeypatch.setenv("DGPPO_NO_WAVE_ENV_KERNEL", "1")
+        ref = _run_step(cfg, ocfg, agent, goal, obst, hits, action, cuda)
+        ref_sense = _run_step(cfg, ocfg, agent, goal, obst, None, None, cuda)
+        monkeypatch.delenv("DGPPO_NO_WAVE_ENV_KERNEL")
+        for got, want, tag in ((fast, ref, "step"), (fast_sense, ref_sense, "sense")):
+            for k in ("next_agent", "next_hits") + (("reward", "cost") if tag == "step" else ()):
+                np.testing.assert_array_equal(got[k].view(np.uint32), want[k].view(np.uint32), err_msg=f"{tag} {k}")
+            _assert_graph_equal(got["graph"], want["graph"])
+    assert np.isnan(fast["cost"][5, 0, 1]) and np.isfinite(fast["cost"][6]).all()
+    # materialise-only mode
+    from dgppo_amd import ops_env as O
+    g1, g2 = O.alloc_graph(cfg, B, cuda), O.alloc_graph(cfg, B, cuda)
+    h = fast["next_hits"]
+    O.graph_materialize(cfg, _to(fast["next_agent"], cuda), _to(goal, cuda), _to(obst, cuda), _to(h, cuda), g1)
+    monkeypatch.setenv("DGPPO_NO_WAVE_ENV_KERNEL", "1")
+    O.graph_materialize(cfg, _to(fast["next_agent"], cuda), _to(goal, cuda), _to(obst, cuda), _to(h, cuda), g2)
+    monkeypatch.delenv("DGPPO_NO_WAVE_ENV_KERNEL")
+    torch.cuda.synchronize()
+    _assert_graph_equal({k: v.cpu().numpy() for k, v in g1.items()}, {k: v.cpu().numpy() for k, v in g2.items()})
+    _assert_graph_equal({k: v.cpu().numpy() for k, v in g1.items()}, fast["graph"])
+    # and the oracle (double integrator: bit-exact; the bicycle's dynamics are compared elsewhere within 1e-6)
+    if not ocfg.is_bicycle:
+        want = E.env_step(ocfg, agent, goal, obst, hits, action, tab)
+        for k in ("next_agent", "next_hits", "reward", "cost"):
+            np.testing.assert_array_equal(fast[k].view(np.uint32), want[k].view(np.uint32), err_msg=k)
+        _assert_graph_equal(fast["graph"], want["graph"])
+        # the corner cases were really there: an agent with all-zero alphas, and all-miss agents
+        p = want["next_agent"][0, 0, :2]
+        assert np.all(want["next_hits"][0, 0] == p), "agent inside an obstacle: all hit points collapse onto the agent"
+        assert (np.abs(want["next_hits"]) > 1e5).any()
