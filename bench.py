@@ -88,18 +88,28 @@ def roofline_env_kernel(cfg, device, B, iters=50):
     W_min = 4 * (n * sd + 2 * n * k + 1 + n * 2) + (n * (n + k) + 7) // 8
     B_min = R_ + W_min
     out = {}
+    stream = torch.cuda.Stream(device)
     for name, graph, bytes_per in (("api", g, B_api), ("compact", None, B_min)):
-        for _ in range(5):
-            OE.env_step(cfg, agent, action, goal, obst, hits, rc, rs, nx, nh, rew, cost, graph)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            OE.env_step(cfg, agent, action, goal, obst, hits, rc, rs, nx, nh, rew, cost, graph)
-        e1.record()
-        torch.cuda.synchronize()
+        # The launches are captured into ONE HIP graph and replayed: with ~15-20 us of Python per ctypes call an eager loop
+        # would time the host, not a ~20 us kernel.  HIP events on the stream the graph runs on bracket the replay.
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                OE.env_step(cfg, agent, action, goal, obst, hits, rc, rs, nx, nh, rew, cost, graph)
+            stream.synchronize()
+            hg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hg, stream=stream, capture_error_mode="thread_local"):
+                for _ in range(iters):
+                    OE.env_step(cfg, agent, action, goal, obst, hits, rc, rs, nx, nh, rew, cost, graph)
+            hg.replay()                                   # first replay uploads the graph
+            stream.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            hg.replay()
+            e1.record(stream)
+            stream.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
         out[name] = dict(us_per_launch=us, bytes_per_env_step=bytes_per, gbs=bytes_per * B / us / 1e3,
-                         env_steps_per_s=B / us * 1e6)
+                         env_steps_per_s=B / us * 1e6, launches_timed=iters)
     return out
 
 

@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdgppo_hip.so")
+# DGPPO_HIP_LIB: developer override (the stamps build of tools/stamps_wave.py); the default is the in-tree library
+LIB_PATH = os.environ.get("DGPPO_HIP_LIB") or os.path.join(_HERE, "csrc", "libdgppo_hip.so")
 
 ABI_VERSION = 2
 OPT_STATE_FLOATS = 8 + 2 * 256     # DGPPO_OPT_STATE_FLOATS (include/dgppo_hip.h)

@@ -33,11 +33,31 @@
 #include "env_step.h"
 #include <stdlib.h>
 
+// minimum waves per SIMD the register allocator must leave room for (VGPR budget 512 / n, granule 8)
+#ifndef DGPPO_WAVE_WPE
+#define DGPPO_WAVE_WPE 5
+#endif
+#ifndef DGPPO_WAVE_UNROLL_O
+#define DGPPO_WAVE_UNROLL_O 8
+#endif
+#define DGPPO_PRAGMA_(x) _Pragma(#x)
+#define DGPPO_PRAGMA(x) DGPPO_PRAGMA_(x)
+
 namespace {
 
 // compiler-level ordering between phases of one wave: DS instructions of a wave execute in issue order, so a later
 // ds_read observes an earlier ds_write of ANY lane of the same wave; only the compiler must not reorder them
 #define WSYNC() asm volatile("" ::: "memory")
+// phase markers: an assembler comment (free) and, in a -DDGPPO_STAMPS build (make stamps; tools/stamps_wave.py), an
+// s_memtime stamp of wave 0's first environment
+#ifdef DGPPO_STAMPS
+__device__ unsigned long long g_wstamps[64];
+__device__ unsigned long long g_wspan[3 * 8192];   // per wave: kernel entry, first env start, last env end (s_memtime)
+#define PHASE(name, idx) do { asm volatile("; PHASE " name ::: "memory"); \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_on) g_wstamps[idx] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PHASE(name, idx) do { } while (0)    // (a marker with a "memory" clobber would also fence the scheduler)
+#endif
 
 constexpr int ceil4(int x) { return (x + 3) / 4 * 4; }
 
@@ -65,20 +85,20 @@ struct alignas(16) WaveLds {
   float4 as[NA * NO * 4];             // per (agent, segment): ax = x1 - x3, ay = y1 - y3, na = ey ax - ex ay
   float4 circ[NO];                    // cull circle: cx, cy, (R + h + 0.05)^2
   float next[ceil4(NA * SD)];         // state at t+1
-  float agent[ceil4(NA * SD)];        // state at t
-  float goal[ceil4(NA * SD)];
-  float act[ceil4(NA * 2)];           // clipped action
+  // inputs of the env, staged with ONE 16-byte load per lane: consecutive float4 items agent | goal | obst | hits | act
+  float agent[NA * SD];               // state at t
+  float goal[NA * SD];
   float obst[NO * 16];
-  float hpre[NA * C::K * 2];          // hit points of graph_t
-  float hnext[NA * C::K * 2];         // hit points of graph_{t+1}
+  float hits[NA * C::K * 2];          // hit points of graph_t until the cost terms are done, then those of graph_{t+1}
+  float act[ceil4(NA * 2)];           // raw action (clipped where it is read)
   float fa[NA * 4];                   // state2feat(next agent)
   float fg[NA * 4];
   float ino[ceil4(NA * NO)];          // start-inside flags
   float red[ceil4(3 * NA)];           // reward terms: d2g | indicator | ||a||^2
   float cost[ceil4(NA * 2)];
+  uint32_t tk[64];                    // top-k slot lists: 32 keys per half-wave (one agent each)
   float sq[4 * NA];                   // squared minima awaiting ONE square root: agent-agent | agent-hit | goal-agent | ||a||^2
-  float states[ceil4(C::N * SD)];     // [N, SD] image
-  float nodes[ceil4(C::N * C::ND)];   // [N, ND] image
+  float nodes[ceil4(C::N * C::ND)];   // [N, ND] image; the [N, SD] states are its leading columns (pad row: -1)
 };
 
 __device__ inline float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -121,8 +141,10 @@ __device__ inline float group_min(float x) {
   return x;
 }
 
-template <int SD, bool SPREAD, int NA, int NO, int WPB>
-__global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
+// MODE / GRAPH are compile-time: the training rollout (MODE_STEP, compact), the API step (MODE_STEP + GraphsTuple), the
+// sense-only pass of reset and the materialise-only pass each get their own straight-line code
+template <int SD, bool SPREAD, int NA, int NO, int WPB, int MODE, bool GRAPH>
+__global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(DGPPO_WAVE_WPE, 8))) lidar_wave_kernel(StepArgs a) {
   using C = WC<SD, SPREAD, NA, NO>;
   using LT = WaveLds<SD, SPREAD, NA, NO>;
   constexpr int K = C::K, ND = C::ND, N = C::N, PAD = C::PAD, NIT = C::NIT, GS = C::GS, E = C::E;
@@ -130,28 +152,54 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
   int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   LT& L = reinterpret_cast<LT*>(smem4)[wave];
+#ifdef DGPPO_STAMPS
+  const int gw = blockIdx.x * WPB + wave;
+  if ((threadIdx.x & 63) == 0 && gw < 8192) g_wspan[3 * gw] = __builtin_amdgcn_s_memtime();
+#endif
   const dgppo_env_cfg& c = a.cfg;
-  const bool do_dyn = (a.mode == MODE_STEP);
-  const bool do_sense = (a.mode != MODE_GRAPH);
+  constexpr bool do_dyn = (MODE == MODE_STEP);
+  constexpr bool do_sense = (MODE != MODE_GRAPH);
+  constexpr bool has_graph = GRAPH;
   const float sr = c.comm_radius;
   const int r = lane & 31;                      // this lane's ray, for the whole kernel
   const int hi_half = lane >> 5;                // which of the two agents of a wave iteration
   const float cr = do_sense ? a.ray_cos[r] : 0.0f, sn = do_sense ? a.ray_sin[r] : 0.0f;
   const uint32_t below = (1u << r) - 1u;        // lanes of my half with a smaller ray index
 
-  // ---- once per wave: the constant part of the node / state images (lidar_env/base.py:236-264, graph.py:214-218) ----
-  for (int i = lane; i < ceil4(N * ND); i += 64) L.nodes[i] = 0.0f;
-  for (int i = lane; i < ceil4(N * SD); i += 64) L.states[i] = 0.0f;
-  WSYNC();
-  for (int node = lane; node < N; node += 64) {
-    if (node < NA) L.nodes[node * ND + SD + 2] = 1.0f;
-    else if (node < 2 * NA) L.nodes[node * ND + SD + 1] = 1.0f;
-    else if (node < PAD) L.nodes[node * ND + SD] = 1.0f;
-    else {
+  // ---- input staging plan: item q (a float4) of the concatenation agent | goal | obst | hits | act of one env ----
+  constexpr int I_AG = NA * SD / 4, I_OB = NO * 4, I_HI = (MODE != MODE_SENSE) ? NA * K * 2 / 4 : 0,
+                I_AC = (MODE == MODE_STEP) ? NA * 2 / 4 : 0;
+  constexpr int IT = 2 * I_AG + I_OB + I_HI + I_AC, NSLOT = (IT + 63) / 64;
+  static_assert(MODE != MODE_STEP || (NA * 2) % 4 == 0, "the action block is staged as float4");
+  const char* gsrc[NSLOT];
+  uint32_t gstride[NSLOT];
+  float4 pf[NSLOT];
 #pragma unroll
-      for (int d = 0; d < SD; ++d) L.states[node * SD + d] = -1.0f;   // pad row, graph.py:217
+  for (int j = 0; j < NSLOT; ++j) {
+    const int q = j * 64 + lane;
+    const char* base = reinterpret_cast<const char*>(a.agent);
+    uint32_t stride = NA * SD * 4;
+    int q0 = 0;
+    if (q >= I_AG) { base = reinterpret_cast<const char*>(a.goal); q0 = I_AG; }
+    if (q >= 2 * I_AG) { base = reinterpret_cast<const char*>(a.obst); stride = NO * 64; q0 = 2 * I_AG; }
+    if (I_HI > 0 && q >= 2 * I_AG + I_OB) { base = reinterpret_cast<const char*>(a.hits); stride = NA * K * 8; q0 = 2 * I_AG + I_OB; }
+    if (I_AC > 0 && q >= 2 * I_AG + I_OB + I_HI) { base = reinterpret_cast<const char*>(a.action); stride = NA * 8; q0 = 2 * I_AG + I_OB + I_HI; }
+    gsrc[j] = base + (q - q0) * 16;
+    gstride[j] = stride;
+  }
+  {
+    const int b0 = blockIdx.x * WPB + wave;          // the first env's inputs fly while the images are initialised
+    if (b0 < a.B) {
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j)
+        if (j * 64 + lane < IT) pf[j] = *reinterpret_cast<const float4*>(gsrc[j] + (size_t)b0 * gstride[j]);
     }
   }
+  // ---- once per wave: the constant part of the node / state images (lidar_env/base.py:236-264, graph.py:214-218) ----
+  for (int i = lane; i < ceil4(N * ND); i += 64) L.nodes[i] = 0.0f;
+  WSYNC();
+  for (int node = lane; node < PAD; node += 64)
+    L.nodes[node * ND + ((node < NA) ? SD + 2 : ((node < 2 * NA) ? SD + 1 : SD))] = 1.0f;
   WSYNC();
 
   for (int b = blockIdx.x * WPB + wave; b < a.B; b += gridDim.x * WPB) {
@@ -159,36 +207,33 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
     // unrolled) body is hoisted out of this loop and kept live — ~170 VGPRs, 3 waves per SIMD; recomputing them costs a
     // few dozen VALU instructions per env and keeps the kernel under 128
     asm volatile("" : "+v"(lane));
-    // ---- P0: stage the env's inputs (16-byte loads; the per-env blocks are 16-byte aligned for these sizes) ----
+#ifdef DGPPO_STAMPS
+    const bool stamp_on = (b == 0);
+    if ((threadIdx.x & 63) == 0 && gw < 8192 && b == gw) g_wspan[3 * gw + 1] = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_on) g_wstamps[40] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+#endif
+    PHASE("P0_stage", 0);
+    // ---- P0: the env's inputs arrive in registers (issued one env ahead), one ds_write_b128 per lane and slot ----
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j)
+      if (j * 64 + lane < IT) reinterpret_cast<float4*>(L.agent)[j * 64 + lane] = pf[j];
     {
-      const float4* ag4 = reinterpret_cast<const float4*>(a.agent + (size_t)b * NA * SD);
-      const float4* go4 = reinterpret_cast<const float4*>(a.goal + (size_t)b * NA * SD);
-      for (int i = lane; i < NA * SD / 4; i += 64) {
-        reinterpret_cast<float4*>(L.agent)[i] = ag4[i];
-        reinterpret_cast<float4*>(L.goal)[i] = go4[i];
-      }
-      if (do_dyn) {
-        const float2* ac2 = reinterpret_cast<const float2*>(a.action + (size_t)b * NA * 2);
-        for (int i = lane; i < NA; i += 64) {
-          const float2 u = ac2[i];
-          reinterpret_cast<float2*>(L.act)[i] = make_float2(clampf(u.x, -1.0f, 1.0f), clampf(u.y, -1.0f, 1.0f));  // env/base.py:84-86
-        }
-      }
-      const float4* ob4 = reinterpret_cast<const float4*>(a.obst + (size_t)b * NO * 16);
-      for (int i = lane; i < NO * 4; i += 64) reinterpret_cast<float4*>(L.obst)[i] = ob4[i];
-      if (a.hits != nullptr) {
-        const float4* hp4 = reinterpret_cast<const float4*>(a.hits + (size_t)b * NA * K * 2);
-        for (int i = lane; i < NA * K * 2 / 4; i += 64) reinterpret_cast<float4*>(L.hpre)[i] = hp4[i];
+      const int bn = b + gridDim.x * WPB;            // prefetch the next env of this wave while this one is processed
+      if (bn < a.B) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          if (j * 64 + lane < IT) pf[j] = *reinterpret_cast<const float4*>(gsrc[j] + (size_t)bn * gstride[j]);
       }
     }
     WSYNC();
+    PHASE("P1a_dyn_seg_circ", 1);
     // ---- P1a: dynamics + features (lanes < NA), goal features (lanes 32..), segment constants, cull circles ----
     if (lane < NA) {
       const int i = lane;
       const float* x = L.agent + i * SD;
       float nx[SD];
       if (do_dyn) {
-        const float u0 = L.act[i * 2], u1 = L.act[i * 2 + 1];
+        const float u0 = clampf(L.act[i * 2], -1.0f, 1.0f), u1 = clampf(L.act[i * 2 + 1], -1.0f, 1.0f);   // env/base.py:84-86
         const float dt = c.dt, A = c.area_size;
         if constexpr (SD == 5) {  // lidar_bicycle_target.py:95-107
           const float theta = atan2f(x[3], x[2]);
@@ -245,6 +290,7 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
       }
     }
     WSYNC();
+    PHASE("P1b_far_as", 2);
     // ---- P1b: (agent, obstacle) start-inside flags + cull bits, (agent, segment) terms, pre-step distances ----
     uint64_t far[C::NFAR];
     if (do_sense) {
@@ -276,6 +322,7 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
 #pragma unroll
       for (int w = 0; w < C::NFAR; ++w) far[w] = 0ull;
     }
+    PHASE("P1c_cost_terms", 3);
     if (do_dyn) {  // cost and reward terms on the PRE-step graph (lidar_env/base.py:170-171,180-207; lidar_spread.py:35-52)
       // The reference takes min_j sqrt(s_j); the correctly rounded square root is monotone, so min_j fl(sqrt(s_j)) ==
       // fl(sqrt(min_j s_j)) bit for bit: reduce the SQUARED distances and take one root per agent afterwards (the root is
@@ -296,7 +343,7 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
         const int q = q0 + lane, i = q / K;
         float d = __builtin_inff();
         if (q < NA * K) {
-          const float dx = L.hpre[q * 2] - L.agent[i * SD], dy = L.hpre[q * 2 + 1] - L.agent[i * SD + 1];
+          const float dx = L.hits[q * 2] - L.agent[i * SD], dy = L.hits[q * 2 + 1] - L.agent[i * SD + 1];
           d = dx * dx + dy * dy;
         }
         const float mo2 = group_min<K>(d);
@@ -344,6 +391,7 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
       }
     }
     WSYNC();
+    PHASE("P1d_reward", 4);
     if (do_dyn) {
       // reward: three sequential sums in index order (the oracle's seq_sum), one per lane, then combined on lane 0
       float s = 0.0f;
@@ -364,142 +412,21 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
       }
       if (lane < NA * 2) a.cost[(size_t)b * NA * 2 + lane] = L.cost[lane];
     }
-    // ---- P2 + P3: per wave iteration, two agents x 32 rays: segment tests (obstacle.py:97-105) -> alpha -> stable
-    //      top-k (env/utils.py:132-136) -> hit points patched into hnext and the node / state images ----
-    if (do_sense) {
-#pragma unroll(NIT <= 4 ? NIT : 1)
-      for (int it = 0; it < NIT; ++it) {
-        const int i = it * 2 + hi_half;
-        const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
-        const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
-        const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
-        float amin = 1e6f, is_in = 0.0f;
-        bool bad = false;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) is_in = fmaxf(is_in, L.ino[i * NO + o]);
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-          const int qa = (it * 2) * NO + o, qb = (it * 2 + 1) * NO + o;
-          const bool fa_ = (far[qa >> 6] >> (qa & 63)) & 1ull, fb_ = (far[qb >> 6] >> (qb & 63)) & 1ull;
-          if (fa_ && fb_) continue;                  // wave-uniform: neither agent of this iteration can reach obstacle o
-          float4 sg[4], as[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) { sg[m] = L.seg[o * 4 + m]; as[m] = L.as[(i * NO + o) * 4 + m]; }
-          float naf[4], adet[4];
-          bool valid[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const float det0 = dx12 * sg[m].w - dy12 * sg[m].z;
-            const float nb = ndy12 * as[m].x + dx12 * as[m].y;
-            // flip both numerators by the sign of det: (na/det, nb/det) == (na'/|det|, nb'/|det|), exactly
-            const uint32_t sb = __float_as_uint(det0) & 0x80000000u;
-            naf[m] = __uint_as_float(__float_as_uint(as[m].z) ^ sb);
-            const float nbf = __uint_as_float(__float_as_uint(nb) ^ sb);
-            adet[m] = __builtin_amdgcn_fmed3f(fabsf(det0), 1e-7f, 1e7f);      // clip(|det|, 1e-7, 1e7)
-            const float mn = raw_min(naf[m], nbf), mx = raw_max(naf[m], nbf);
-            // 0 <= q <= 1 for both quotients  <=>  0 <= min(na', nb') and max(na', nb') <= |det|   (-0 >= 0 holds, like -0/d >= 0)
-            valid[m] = (mn >= 0.0f) && (mx <= adet[m]);
-            bad = bad || !(det0 != 0.0f);                                      // zero or NaN
-          }
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            if (__builtin_amdgcn_ballot_w64(valid[m]) != 0ull) {              // wave-uniform: skip the division when no lane hits
-              const float qa_ = naf[m] / adet[m] + 0.0f;                      // v*alpha + (1-v)*1e6 with v = 1 (turns -0 into +0)
-              const float al = valid[m] ? qa_ : 1e6f;
-              amin = raw_min(amin, al);
-            }
-          }
-        }
-        float ar = amin;
-        if (bad) {                         // literal reference arithmetic for every segment of this lane (see lidar_step_kernel)
-          float lmin = 1e6f;
-          bool any_nan = false;
-          for (int q = 0; q < NO * 4; ++q) {
-            const float4 sgq = L.seg[q];
-            const float4 asq = L.as[i * NO * 4 + q];
-            const float det0 = dx12 * sgq.w - dy12 * sgq.z;
-            const float nb = ndy12 * asq.x + dx12 * asq.y;
-            const float sgn = (det0 > 0.0f) ? 1.0f : ((det0 < 0.0f) ? -1.0f : det0);
-            const float dz = sgn * fminf(fmaxf(fabsf(det0), 1e-7f), 1e7f);
-            const float aq = asq.z / dz, bq = nb / dz;
-            const float v = ((aq <= 1.0f) && (aq >= 0.0f) && (bq <= 1.0f) && (bq >= 0.0f)) ? 1.0f : 0.0f;
-            const float al = v * aq + (1.0f - v) * 1e6f;
-            any_nan = any_nan || (al != al);
-            lmin = fminf(lmin, al);
-          }
-          ar = any_nan ? __builtin_nanf("") : lmin;
-        }
-        ar = ar * (1.0f - is_in);
-        // sort key: float bits (alphas are >= +0), NaN -> max.  Classes: L (hit, key < 1e6), M (miss, key == 1e6), H (NaN)
-        const uint32_t kr = (ar != ar) ? 0xFFFFFFFFu : __float_as_uint(ar);
-        const uint64_t Lm = __builtin_amdgcn_ballot_w64(kr < MISS_BITS);
-        const uint64_t Mm = __builtin_amdgcn_ballot_w64(kr == MISS_BITS);
-        const uint64_t Zm = __builtin_amdgcn_ballot_w64(kr == 0u);
-        uint32_t lo = (uint32_t)Lm, hi = (uint32_t)(Lm >> 32);
-        const uint32_t myL = hi_half ? hi : lo;
-        const uint32_t myM = hi_half ? (uint32_t)(Mm >> 32) : (uint32_t)Mm;
-        const int cntL = __popc(myL);
-        // misses keep ray order behind all hits; NaNs behind the misses (stable ascending sort)
-        const int rank_other = (kr == MISS_BITS) ? cntL + __popc(myM & below)
-                                                 : cntL + __popc(myM) + __popc(~(myL | myM) & below);
-        // an agent that starts inside an obstacle has all 32 alphas == 0: ranks are the ray indices
-        const bool z_lo = ((uint32_t)Zm == 0xFFFFFFFFu), z_hi = ((uint32_t)(Zm >> 32) == 0xFFFFFFFFu);
-        if (z_lo) lo = 0u;
-        if (z_hi) hi = 0u;
-        int rankL = 0;
-        while ((lo | hi) != 0u) {          // wave-uniform loop over the hitting lanes, one of each half per trip
-          const int jl = lo ? __builtin_ctz(lo) : 0, jh = hi ? __builtin_ctz(hi) : 0;
-          const uint32_t kl = (uint32_t)__builtin_amdgcn_readlane((int)kr, jl);
-          const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)kr, 32 + jh);
-          const bool vl = (lo != 0u), vh = (hi != 0u);
-          const uint32_t kj = hi_half ? kh : kl;
-          const int jj = hi_half ? jh : jl;
-          const bool vj = hi_half ? vh : vl;
-          rankL += (vj && (kj < kr || (kj == kr && jj < r))) ? 1 : 0;
-          lo &= lo - 1u;
-          hi &= hi - 1u;
-        }
-        const bool allz = hi_half ? z_hi : z_lo;
-        const int rank = allz ? r : ((kr < MISS_BITS) ? rankL : rank_other);
-        if (rank < K) {
-          const float hx = x1 + (x2 - x1) * ar, hy = y1 + (y2 - y1) * ar;
-          const int hq = i * K + rank, node = 2 * NA + hq;
-          L.hnext[hq * 2] = hx; L.hnext[hq * 2 + 1] = hy;
-          L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
-          L.states[node * SD] = hx; L.states[node * SD + 1] = hy;
-        }
-      }
-    } else {
-      // materialise-only: the hit points are given
-      for (int q = lane; q < NA * K; q += 64) {
-        const float hx = L.hpre[q * 2], hy = L.hpre[q * 2 + 1];
-        const int node = 2 * NA + q;
-        L.hnext[q * 2] = hx; L.hnext[q * 2 + 1] = hy;
-        L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
-        L.states[node * SD] = hx; L.states[node * SD + 1] = hy;
-      }
-    }
-    if (a.has_graph) {                     // agent / goal rows of the images
-      for (int q = lane; q < NA * SD; q += 64) {
-        const int node = q / SD, d = q - node * SD;
-        const float va = L.next[q], vg = L.goal[q];
-        L.nodes[node * ND + d] = va; L.states[q] = va;
-        L.nodes[(NA + node) * ND + d] = vg; L.states[NA * SD + q] = vg;
-      }
-    }
-    WSYNC();
-    // ---- P4: compact outputs ----
+    // ---- early outputs: everything that does not depend on the ray-cast leaves now, so that these stores drain while
+    //      the segment tests run (at one env per wave all waves reach their stores at the same time otherwise) ----
     if (a.next_agent != nullptr) {
       float4* o4 = reinterpret_cast<float4*>(a.next_agent + (size_t)b * NA * SD);
       for (int i = lane; i < NA * SD / 4; i += 64) o4[i] = reinterpret_cast<const float4*>(L.next)[i];
     }
-    if (a.next_hits != nullptr) {
-      float4* o4 = reinterpret_cast<float4*>(a.next_hits + (size_t)b * NA * K * 2);
-      for (int i = lane; i < NA * K * 2 / 4; i += 64) o4[i] = reinterpret_cast<const float4*>(L.hnext)[i];
+    if (has_graph) {                     // agent / goal rows of the images
+      for (int q = lane; q < NA * SD; q += 64) {
+        const int node = q / SD, d = q - node * SD;
+        const float va = L.next[q], vg = L.goal[q];
+        L.nodes[node * ND + d] = va;
+        L.nodes[(NA + node) * ND + d] = vg;
+      }
     }
-    if (!a.has_graph) continue;
-    // ---- P5: padded GraphsTuple (lidar_env/base.py:227-271, lidar_spread.py:57-96, lidar_target.py:57-96, graph.py:35-44,212-247)
-    {
+    if (has_graph) {
       float4* edges = reinterpret_cast<float4*>(a.g.edges) + (size_t)b * E;
       int32_t* recv = a.g.receivers + (size_t)b * E;
       int32_t* send = a.g.senders + (size_t)b * E;
@@ -529,18 +456,6 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
           send[NA * NA + q] = NA + g;
         }
       }
-#pragma unroll
-      for (int q0 = 0; q0 < NA * K; q0 += 64) {      // agent-hit block
-        const int q = q0 + lane;
-        if (q < NA * K) {
-          const int i = q / K;
-          const float lx = L.next[i * SD] - L.hnext[q * 2], ly = L.next[i * SD + 1] - L.hnext[q * 2 + 1];
-          const bool mask = lx * lx + ly * ly < a.thr2_lidar;      // sqrt(s) < comm_radius - 0.1, as above
-          edges[NA * NA + NA * GS + q] = make_float4(lx, ly, 0.0f, 0.0f);
-          recv[NA * NA + NA * GS + q] = mask ? i : PAD;
-          send[NA * NA + NA * GS + q] = mask ? 2 * NA + q : PAD;
-        }
-      }
       int32_t* nty = a.g.node_type + (size_t)b * N;
 #pragma unroll
       for (int q0 = 0; q0 < N; q0 += 64) {
@@ -548,29 +463,210 @@ __global__ void __launch_bounds__(WPB * 64) lidar_wave_kernel(StepArgs a) {
         if (node < N) nty[node] = (node < NA) ? 0 : ((node < 2 * NA) ? 1 : ((node < PAD) ? 2 : -1));
       }
       if (lane == 0) { a.g.n_node[b] = N; a.g.n_edge[b] = E; }
+    }
+    PHASE("P2_rays", 5);
+    // ---- P2 + P3: per wave iteration, two agents x 32 rays: segment tests (obstacle.py:97-105) -> alpha -> stable
+    //      top-k (env/utils.py:132-136) -> hit points patched into hnext and the node / state images ----
+    if (do_sense) {
+#pragma unroll(NIT <= 4 ? NIT : 1)
+      for (int it = 0; it < NIT; ++it) {
+        const int i = it * 2 + hi_half;
+        const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
+        const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
+        const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
+        float amin = 1e6f, is_in = 0.0f;
+        bool bad = false;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) is_in = fmaxf(is_in, L.ino[i * NO + o]);
+DGPPO_PRAGMA(unroll DGPPO_WAVE_UNROLL_O)
+        for (int o = 0; o < NO; ++o) {
+          const int qa = (it * 2) * NO + o, qb = (it * 2 + 1) * NO + o;
+          const bool fa_ = (far[qa >> 6] >> (qa & 63)) & 1ull, fb_ = (far[qb >> 6] >> (qb & 63)) & 1ull;
+          if (fa_ && fb_) continue;                  // wave-uniform: neither agent of this iteration can reach obstacle o
+          float4 sg[4], as[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) { sg[m] = L.seg[o * 4 + m]; as[m] = L.as[(i * NO + o) * 4 + m]; }
+          float naf[4], adet[4];
+          bool valid[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float det0 = dx12 * sg[m].w - dy12 * sg[m].z;
+            const float nb = ndy12 * as[m].x + dx12 * as[m].y;
+            // flip both numerators by the sign of det: (na/det, nb/det) == (na'/|det|, nb'/|det|), exactly
+            const uint32_t sb = __float_as_uint(det0) & 0x80000000u;
+            naf[m] = __uint_as_float(__float_as_uint(as[m].z) ^ sb);
+            const float nbf = __uint_as_float(__float_as_uint(nb) ^ sb);
+            adet[m] = __builtin_amdgcn_fmed3f(fabsf(det0), 1e-7f, 1e7f);      // clip(|det|, 1e-7, 1e7)
+            const float mn = raw_min(naf[m], nbf), mx = raw_max(naf[m], nbf);
+            // 0 <= q <= 1 for both quotients  <=>  0 <= min(na', nb') and max(na', nb') <= |det|   (-0 >= 0 holds, like -0/d >= 0)
+            valid[m] = (mn >= 0.0f) && (mx <= adet[m]);
+            bad = bad || !(det0 != 0.0f);                                      // zero or NaN
+          }
+          // one wave-uniform branch per obstacle: when some lane hits some segment, the four correctly rounded divisions
+          // are issued together (independent chains interleave) instead of one dependent chain per branch
+          if (__builtin_amdgcn_ballot_w64(valid[0] || valid[1] || valid[2] || valid[3]) != 0ull) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const float qa_ = naf[m] / adet[m] + 0.0f;                      // v*alpha + (1-v)*1e6 with v = 1 (turns -0 into +0)
+              const float al = valid[m] ? qa_ : 1e6f;
+              amin = raw_min(amin, al);
+            }
+          }
+        }
+        PHASE("P2_slowcheck", 12 + it * 3);
+        float ar = amin;
+        if (bad) {                         // literal reference arithmetic for every segment of this lane (see lidar_step_kernel)
+          float lmin = 1e6f;
+          bool any_nan = false;
+#pragma unroll 1
+          for (int q = 0; q < NO * 4; ++q) {
+            const float4 sgq = L.seg[q];
+            const float4 asq = L.as[i * NO * 4 + q];
+            const float det0 = dx12 * sgq.w - dy12 * sgq.z;
+            const float nb = ndy12 * asq.x + dx12 * asq.y;
+            const float sgn = (det0 > 0.0f) ? 1.0f : ((det0 < 0.0f) ? -1.0f : det0);
+            const float dz = sgn * fminf(fmaxf(fabsf(det0), 1e-7f), 1e7f);
+            const float aq = asq.z / dz, bq = nb / dz;
+            const float v = ((aq <= 1.0f) && (aq >= 0.0f) && (bq <= 1.0f) && (bq >= 0.0f)) ? 1.0f : 0.0f;
+            const float al = v * aq + (1.0f - v) * 1e6f;
+            any_nan = any_nan || (al != al);
+            lmin = fminf(lmin, al);
+          }
+          ar = any_nan ? __builtin_nanf("") : lmin;
+        }
+        ar = ar * (1.0f - is_in);
+        PHASE("P3_topk", 12 + it * 3 + 1);
+        // sort key: float bits (alphas are >= +0), NaN -> max.  Classes: L (hit, key < 1e6), M (miss, key == 1e6), H (NaN)
+        const uint32_t kr = (ar != ar) ? 0xFFFFFFFFu : __float_as_uint(ar);
+        const uint64_t Lm = __builtin_amdgcn_ballot_w64(kr < MISS_BITS);
+        const uint64_t Mm = __builtin_amdgcn_ballot_w64(kr == MISS_BITS);
+        const uint64_t Zm = __builtin_amdgcn_ballot_w64(kr == 0u);
+        const uint32_t lo = (uint32_t)Lm, hi = (uint32_t)(Lm >> 32);
+        const uint32_t myL = hi_half ? hi : lo;
+        const uint32_t myM = hi_half ? (uint32_t)(Mm >> 32) : (uint32_t)Mm;
+        const int cntL = __popc(myL);
+        // misses keep ray order behind all hits; NaNs behind the misses (stable ascending sort)
+        const int rank_other = (kr == MISS_BITS) ? cntL + __popc(myM & below)
+                                                 : cntL + __popc(myM) + __popc(~(myL | myM) & below);
+        // an agent that starts inside an obstacle has all 32 alphas == 0: ranks are the ray indices
+        const bool z_lo = ((uint32_t)Zm == 0xFFFFFFFFu), z_hi = ((uint32_t)(Zm >> 32) == 0xFFFFFFFFu);
+        const bool allz = hi_half ? z_hi : z_lo;
+        const bool isL = (kr < MISS_BITS) && !allz;
+        // Ranks of the hitting rays: every hitting lane puts its key into its half's slot list, compacted in ray order
+        // (slot p = number of hitting rays with a smaller index); each lane then counts the slots with a smaller key,
+        // four slots per trip of a wave-uniform loop bounded by ceil(#hits / 4) <= 8.  Unused slots hold 0xFFFFFFFF.
+        const int p = __popc(myL & below);
+        L.tk[lane] = 0xFFFFFFFFu;
+        WSYNC();
+        if (isL) L.tk[hi_half * 32 + p] = kr;
+        WSYNC();
+        const int c_lo = z_lo ? 0 : __popc(lo), c_hi = z_hi ? 0 : __popc(hi);
+        const int cmax = c_lo > c_hi ? c_lo : c_hi;
+        int rlt = 0;
+#pragma unroll 1
+        for (int cb = 0; cb < cmax; cb += 4) {
+          const uint4 ks = *reinterpret_cast<const uint4*>(&L.tk[hi_half * 32 + cb]);
+          rlt += (ks.x < kr ? 1 : 0) + (ks.y < kr ? 1 : 0) + (ks.z < kr ? 1 : 0) + (ks.w < kr ? 1 : 0);
+        }
+        // equal keys among the hits (two rays with bit-identical alpha) would need the index tie-break: they show up as
+        // two lanes claiming the same strict rank.  Detect through a second pass over the slot list (claim slot rlt with
+        // p, read it back) and only then add the tie-break term; practically never taken.
+        WSYNC();
+        if (isL) L.tk[hi_half * 32 + rlt] = (uint32_t)p;
+        WSYNC();
+        const bool lost = isL && (L.tk[hi_half * 32 + rlt] != (uint32_t)p);
+        if (__builtin_amdgcn_ballot_w64(lost) != 0ull) {
+          WSYNC();
+          L.tk[lane] = 0xFFFFFFFFu;
+          WSYNC();
+          if (isL) L.tk[hi_half * 32 + p] = kr;
+          WSYNC();
+          rlt = 0;
+#pragma unroll 1
+          for (int sl = 0; sl < cmax; ++sl) {
+            const uint32_t kj = L.tk[hi_half * 32 + sl];
+            rlt += (kj < kr || (kj == kr && sl < p)) ? 1 : 0;
+          }
+          WSYNC();
+        }
+        const int rank = allz ? r : (isL ? rlt : rank_other);
+        if (rank < K) {
+          const float hx = x1 + (x2 - x1) * ar, hy = y1 + (y2 - y1) * ar;
+          const int hq = i * K + rank, node = 2 * NA + hq;
+          L.hits[hq * 2] = hx; L.hits[hq * 2 + 1] = hy;
+          L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
+        }
+        PHASE("P3_end", 12 + it * 3 + 2);
+      }
+    } else {
+      // materialise-only: the hit points are given
+      for (int q = lane; q < NA * K; q += 64) {
+        const float hx = L.hits[q * 2], hy = L.hits[q * 2 + 1];
+        const int node = 2 * NA + q;
+        L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
+      }
+    }
+    WSYNC();
+    PHASE("P4_compact", 7);
+    // ---- P4: late compact outputs ----
+    if (a.next_hits != nullptr) {
+      float4* o4 = reinterpret_cast<float4*>(a.next_hits + (size_t)b * NA * K * 2);
+      for (int i = lane; i < NA * K * 2 / 4; i += 64) o4[i] = reinterpret_cast<const float4*>(L.hits)[i];
+    }
+    if (!has_graph) continue;
+    PHASE("P5_graph", 8);
+    // ---- P5: padded GraphsTuple (lidar_env/base.py:227-271, lidar_spread.py:57-96, lidar_target.py:57-96, graph.py:35-44,212-247)
+    {
+      float4* edges = reinterpret_cast<float4*>(a.g.edges) + (size_t)b * E;
+      int32_t* recv = a.g.receivers + (size_t)b * E;
+      int32_t* send = a.g.senders + (size_t)b * E;
+#pragma unroll
+      for (int q0 = 0; q0 < NA * K; q0 += 64) {      // agent-hit block
+        const int q = q0 + lane;
+        if (q < NA * K) {
+          const int i = q / K;
+          const float lx = L.next[i * SD] - L.hits[q * 2], ly = L.next[i * SD + 1] - L.hits[q * 2 + 1];
+          const bool mask = lx * lx + ly * ly < a.thr2_lidar;      // sqrt(s) < comm_radius - 0.1, as above
+          edges[NA * NA + NA * GS + q] = make_float4(lx, ly, 0.0f, 0.0f);
+          recv[NA * NA + NA * GS + q] = mask ? i : PAD;
+          send[NA * NA + NA * GS + q] = mask ? 2 * NA + q : PAD;
+        }
+      }
       float* nodes = a.g.nodes + (size_t)b * N * ND;
 #pragma unroll
       for (int q0 = 0; q0 < N * ND; q0 += 64) {
         const int q = q0 + lane;
         if (q < N * ND) nodes[q] = L.nodes[q];
       }
-      if constexpr ((N * SD) % 4 == 0) {
+      // states [N, SD] = the leading SD columns of the node rows, pad row -1 (lidar_env/base.py:260-264, graph.py:217-218)
+      if constexpr (SD == 4) {
         float4* st4 = reinterpret_cast<float4*>(a.g.states + (size_t)b * N * SD);
 #pragma unroll
-        for (int q0 = 0; q0 < N * SD / 4; q0 += 64) {
-          const int q = q0 + lane;
-          if (q < N * SD / 4) st4[q] = reinterpret_cast<const float4*>(L.states)[q];
+        for (int q0 = 0; q0 < N; q0 += 64) {
+          const int node = q0 + lane;
+          if (node < N) {
+            const float* row = L.nodes + node * ND;
+            st4[node] = (node == PAD) ? make_float4(-1.0f, -1.0f, -1.0f, -1.0f) : make_float4(row[0], row[1], row[2], row[3]);
+          }
         }
       } else {
         float* st = a.g.states + (size_t)b * N * SD;
 #pragma unroll
         for (int q0 = 0; q0 < N * SD; q0 += 64) {
           const int q = q0 + lane;
-          if (q < N * SD) st[q] = L.states[q];
+          if (q < N * SD) {
+            const int node = q / SD, d = q - node * SD;
+            st[q] = (node == PAD) ? -1.0f : L.nodes[node * ND + d];
+          }
         }
       }
     }
     WSYNC();   // the next env patches the images only after this env's reads of them were issued
+    PHASE("env_end", 9);
+#ifdef DGPPO_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_on) g_wstamps[41] = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0 && gw < 8192) g_wspan[3 * gw + 2] = __builtin_amdgcn_s_memtime();
+#endif
   }
 }
 
@@ -582,8 +678,33 @@ bool launch_inst(const StepArgs& a, hipStream_t s) {
   constexpr int WPB = (per_wave * 4 <= 40 * 1024) ? 4 : ((per_wave * 2 <= 52 * 1024) ? 2 : 1);
   static_assert(per_wave * WPB <= 64 * 1024, "LDS slab too large");
   constexpr size_t smem = per_wave * WPB;
-  const int per_cu = (int)((160 * 1024) / smem) < (32 / WPB) ? (int)((160 * 1024) / smem) : (32 / WPB);
-  const int max_blocks = 256 * (per_cu > 0 ? per_cu : 1);
+  // persistent grid = what is actually resident (registers, LDS and wave slots together): ask the runtime once per
+  // instantiation; a larger grid would leave a second, partial round of workgroups behind the first
+  static int per_cu_cached[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  int& per_cu = per_cu_cached[a.mode][a.has_graph ? 1 : 0];
+  if (per_cu == 0) {
+    int n = 0;
+    hipError_t e = hipErrorUnknown;
+#define OCC(M_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lidar_wave_kernel<SD, SPREAD, NA, NO, WPB, M_, G_>, WPB * 64, smem)
+    if (a.mode == MODE_STEP) { if (a.has_graph) OCC(MODE_STEP, true); else OCC(MODE_STEP, false); }
+    else if (a.mode == MODE_SENSE) { if (a.has_graph) OCC(MODE_SENSE, true); else OCC(MODE_SENSE, false); }
+    else OCC(MODE_GRAPH, true);
+#undef OCC
+    per_cu = (e == hipSuccess && n > 0) ? n : 1;
+  }
+  int n_cu = 256;
+  {
+    static int cached_cu = 0;
+    if (cached_cu == 0) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        cached_cu = v;
+      else
+        cached_cu = 256;
+    }
+    n_cu = cached_cu;
+  }
+  const int max_blocks = n_cu * per_cu;
   int blocks = (a.B + WPB - 1) / WPB;
   if (blocks > max_blocks) blocks = max_blocks;
   const char* wpe = getenv("DGPPO_WAVE_ENVS");    // tuning knob: minimum envs per wave (fewer, longer-lived waves)
@@ -591,11 +712,25 @@ bool launch_inst(const StepArgs& a, hipStream_t s) {
     const int want = (a.B + WPB * atoi(wpe) - 1) / (WPB * atoi(wpe));
     if (want >= 1 && want < blocks) blocks = want;
   }
-  hipLaunchKernelGGL((lidar_wave_kernel<SD, SPREAD, NA, NO, WPB>), dim3(blocks), dim3(WPB * 64), smem, s, a);
+  const dim3 g(blocks), t(WPB * 64);
+#define LAUNCH(M_, G_) hipLaunchKernelGGL((lidar_wave_kernel<SD, SPREAD, NA, NO, WPB, M_, G_>), g, t, smem, s, a)
+  if (a.mode == MODE_STEP) { if (a.has_graph) LAUNCH(MODE_STEP, true); else LAUNCH(MODE_STEP, false); }
+  else if (a.mode == MODE_SENSE) { if (a.has_graph) LAUNCH(MODE_SENSE, true); else LAUNCH(MODE_SENSE, false); }
+  else LAUNCH(MODE_GRAPH, true);
+#undef LAUNCH
   return true;
 }
 
 }  // namespace
+
+#ifdef DGPPO_STAMPS
+extern "C" int32_t dgppo_debug_wave_stamps(unsigned long long* out) {
+  return (int32_t)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), sizeof(unsigned long long) * 64);
+}
+extern "C" int32_t dgppo_debug_wave_spans(unsigned long long* out) {
+  return (int32_t)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wspan), sizeof(unsigned long long) * 3 * 8192);
+}
+#endif
 
 bool launch_lidar_wave(const StepArgs& a, hipStream_t s) {
   const dgppo_env_cfg& c = a.cfg;
