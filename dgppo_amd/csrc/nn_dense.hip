@@ -29,6 +29,7 @@ struct DenseArgs {
   int act;         // 0 none, 1 relu
   int accumulate;  // Y += result
   int trans_w;     // use W^T: result[m,n] = sum_k X[m,k] * W[n,k]
+  const float* mask; int ldm;   // optional [M, N]: Y = (mask > 0) ? result : 0  — the ReLU backward of the layer whose output `mask` is
 };
 
 
@@ -195,7 +196,10 @@ __global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
           float v = acc[r][t][j] + bias[t];
           if constexpr (ACC) v += yold[r][t][j];
           if (a.act == 1) v = fmaxf(v, 0.0f);
-          if (col < N && row < a.M) a.Y[(size_t)row * a.ldy + col] = v;
+          if (col < N && row < a.M) {
+            if (a.mask != nullptr) v = (a.mask[(size_t)row * a.ldm + col] > 0.0f) ? v : 0.0f;
+            a.Y[(size_t)row * a.ldy + col] = v;
+          }
         }
       }
     }
@@ -601,8 +605,9 @@ int32_t dense_bwd_w_launch(DenseBwdWArgs a, hipStream_t s) {
 
 extern "C" int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, int32_t ldw, const float* bias, float* Y,
                                    int32_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, int32_t accumulate,
-                                   int32_t trans_w, void* stream) {
-  DenseArgs a{X, ldx, W, ldw, bias, Y, ldy, M, K, N, act, accumulate, trans_w};
+                                   int32_t trans_w, const float* relu_mask, int32_t ldm, void* stream) {
+  DGPPO_REQUIRE(relu_mask == nullptr || ldm >= N, "dense: mask leading dimension too small");
+  DenseArgs a{X, ldx, W, ldw, bias, Y, ldy, M, K, N, act, accumulate, trans_w, relu_mask, ldm};
   return dense_fwd_launch(a, (hipStream_t)stream);
 }
 

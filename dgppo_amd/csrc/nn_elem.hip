@@ -673,12 +673,14 @@ extern "C" int32_t dgppo_value_loss(const float* v, const float* target, float* 
 // ---------------------------------------------------------------------------------------------------------------------
 // mean over the agents of a graph (value.py:33) and its backward; relu backward; small utilities
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void mean_agents_kernel(const float* __restrict__ x, float* __restrict__ y, int G, int n, int D, int backward) {
+__global__ void mean_agents_kernel(const float* __restrict__ x, float* __restrict__ y, int G, int n, int D, int backward,
+                                   const float* __restrict__ relu_mask) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (backward) {  // x = dP [G, D] -> y = dX [G, n, D]
+  if (backward) {  // x = dP [G, D] -> y = dX [G, n, D]  (optionally through the ReLU whose output is relu_mask)
     if (idx >= G * n * D) return;
     const int d = idx % D, g = idx / (n * D);
-    y[idx] = x[(size_t)g * D + d] / (float)n;
+    const float v = x[(size_t)g * D + d] / (float)n;
+    y[idx] = (relu_mask == nullptr || relu_mask[idx] > 0.0f) ? v : 0.0f;
   } else {
     if (idx >= G * D) return;
     const int d = idx % D, g = idx / D;
@@ -689,12 +691,13 @@ __global__ void mean_agents_kernel(const float* __restrict__ x, float* __restric
 }
 
 extern "C" int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_t D, int32_t backward,
-                                     void* stream) {
+                                     const float* relu_mask, void* stream) {
   DGPPO_REQUIRE(G >= 0 && n >= 1 && D >= 1, "mean_agents: bad sizes");
   if (G == 0) return 0;
   DGPPO_REQUIRE(x && y, "mean_agents: NULL operand");
   const long total = backward ? (long)G * n * D : (long)G * D;
-  hipLaunchKernelGGL(mean_agents_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, G, n, D, backward);
+  hipLaunchKernelGGL(mean_agents_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, G, n, D, backward,
+                     backward ? relu_mask : nullptr);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

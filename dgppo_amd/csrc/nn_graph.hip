@@ -216,6 +216,7 @@ struct AttnArgs {
   float* dqt;            // [G*n, H*F]
   float* dXa;            // [G*n, F]   (written, not accumulated) or NULL
   float* dXo;            // [G*(Ns-n), F] or NULL
+  int relu_xo;           // dXo *= (Xo > 0): Xo is the ReLU output of the previous layer's update (gnn.py:109-111, aggr = 0)
   int G;
 };
 
@@ -1093,7 +1094,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
           const int f = ft * 16 + li;
           if (node >= Ns || f >= F) continue;
           if (node < n) a.dXa[((size_t)g * n + node) * F + f] = dxacc[ct][ft][r] + dzc[node * Kp + f];
-          else if (a.dXo != nullptr) a.dXo[((size_t)g * (Ns - n) + (node - n)) * F + f] = dxacc[ct][ft][r];
+          else if (a.dXo != nullptr) {
+            const size_t o = ((size_t)g * (Ns - n) + (node - n)) * F + f;
+            float v = dxacc[ct][ft][r];
+            if (a.relu_xo) v = (a.Xo[o] > 0.0f) ? v : 0.0f;     // the node row was just read as an MFMA fragment: an L2 hit
+            a.dXo[o] = v;
+          }
         }
       }
   }
@@ -1329,12 +1335,14 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
 
 extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
                                   const float* attn, const float* qt, const float* Xa, const float* Xo,
-                                  const float* efeat, float* dqt, float* dXa, float* dXo, int32_t G, void* stream) {
+                                  const float* efeat, float* dqt, float* dXa, float* dXo, int32_t relu_xo, int32_t G,
+                                  void* stream) {
   AttnArgs a{};
   int32_t rc = attn_check(cfg, F, H, Kp, G, a);
   if (rc) return rc;
   if (G == 0) return 0;
   DGPPO_REQUIRE(dzcat && attn && qt && Xa && efeat && dqt, "attn_bwd: NULL operand");
+  a.relu_xo = 0;
   DGPPO_REQUIRE(a.t.Ns == a.t.n || Xo, "attn_bwd: Xo is NULL");
   DGPPO_REQUIRE(!(dXo && !dXa), "attn_bwd: dXo needs dXa");
   a.dzcat = dzcat; a.attn = (float*)attn; a.qt = qt; a.Xa = Xa; a.Xo = Xo; a.efeat = efeat; a.dqt = dqt; a.dXa = dXa; a.dXo = dXo;
@@ -1349,14 +1357,20 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   if ((F & 3) == 0 && t.S <= 64 && (Kp & 3) == 0 && t.n * H * H < 65536 && !getenv("DGPPO_ATTN_VALU") &&
       !getenv("DGPPO_ATTN_BLOCK")) {
     const int grid = (G + 3) / 4, NP = (d.nH + 7) / 8, SJ = (t.S + 7) / 8;
+    a.relu_xo = (relu_xo && dXo) ? 1 : 0;          // fused into the wave kernel's dXo store
     if (F == 8) launched = launch_attn_wave<8>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
+    a.relu_xo = 0;
   }
   if (!launched) {       // workgroup-per-graph fallbacks; among them the VALU kernel wins for narrow layers (measured)
     if ((F & 3) == 0 && F >= 16 && t.S <= 64 && msmem <= 64 * 1024 && !getenv("DGPPO_ATTN_VALU"))
       hipLaunchKernelGGL(attn_bwd_kernel, dim3(G), dim3(256), msmem, (hipStream_t)stream, a);
     else
       hipLaunchKernelGGL(attn_bwd_valu_kernel, dim3(G), dim3(256), smem, (hipStream_t)stream, a);
+    DGPPO_LAUNCH_CHECK();
+    if (relu_xo && dXo)    // the fallback kernels do not fuse the ReLU mask of the other nodes' gradient: separate pass
+      return dgppo_relu_bwd(dXo, Xo, (int64_t)G * (t.Ns - t.n) * F, stream);
+    return 0;
   }
   DGPPO_LAUNCH_CHECK();
   return 0;

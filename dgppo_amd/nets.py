@@ -284,42 +284,46 @@ class Net:
         dy = A.get(f"{tag}.dy", Rh, HID)
         K.dense_fwd(dgi, self.p("gru.Wi"), None, dy, trans_w=True)
         x_in = {1: act["mlp_in"], 2: act["y1"]}
+        top = act[f"Xa{self.gnn_layers}"]          # output of the last GNN layer (a ReLU output): masks the gradient entering it
         for i in (2, 1):
             dpre = A.get(f"{tag}.dpre{i}", Rh, HID)
             K.ln_relu_bwd(act[f"p{i}"], act[f"y{i}"], act[f"st{i}"], self.p(f"mlp.g{i}"), dy, dpre, self.g(f"mlp.g{i}"),
                           self.g(f"mlp.be{i}"))
             K.dense_bwd_w(x_in[i], dpre, self.g(f"mlp.W{i}"), self.g(f"mlp.b{i}"))
             dy = A.get(f"{tag}.dyy{i}", Rh, HID)
-            K.dense_fwd(dpre, self.p(f"mlp.W{i}"), None, dy, trans_w=True)
+            # i == 1 for the per-agent nets: this IS the gradient of the last GNN layer's output -> ReLU backward fused here
+            K.dense_fwd(dpre, self.p(f"mlp.W{i}"), None, dy, trans_w=True,
+                        relu_mask=top if (i == 1 and self.kind != "Vl") else None)
         if self.kind == "Vl":
             dXa = A.get(f"{tag}.dXaL", R, OUT_DIM)
-            K.mean_agents(dy, dXa, G, n, OUT_DIM, backward=True)
+            K.mean_agents(dy, dXa, G, n, OUT_DIM, backward=True, relu_mask=top)
         else:
             dXa = dy
+        # From here on dXa / dXo arrive ALREADY multiplied by relu'(layer output): the kernel that finishes each gradient
+        # applies the mask (dense_fwd / mean_agents / attn_bwd epilogues) instead of a separate elementwise pass.
         dXo = None
         for l in range(self.gnn_layers - 1, -1, -1):
             f, fp, d, kp = self.dims[l]
-            Xa_n = act[f"Xa{l + 1}"]
-            K.relu_bwd(dXa, Xa_n)
             K.dense_bwd_w(act[f"zcat{l}"], dXa, self.pg(f"gnn{l}.Wout"), self.g(f"gnn{l}.bu"))
             dz = A.get(f"{tag}.dz{l}", R, kp)
             K.dense_fwd(dXa, self.pp(f"gnn{l}.Wout"), None, dz, trans_w=True)
             if dXo is not None:  # other nodes of layer l+1: relu(W_u x + b_u)
-                Xo_n = act[f"Xo{l + 1}"]
-                K.relu_bwd(dXo, Xo_n)
                 K.dense_bwd_w(act[f"Xo{l}"], dXo, self.pg(f"gnn{l}.Wout")[:fp], self.g(f"gnn{l}.bu"))
             dqt = A.get(f"{tag}.dqt{l}", R, H_HEADS * fp)
             need_dx = l > 0
             dXa_l = A.get(f"{tag}.dXa{l}", R, fp) if need_dx else None
             dXo_prev = dXo
             dXo_l = A.get(f"{tag}.dXo{l}", Ro, fp) if (need_dx and Ro > 0) else None
+            more_dXo = dXo_prev is not None and dXo_l is not None       # a dense term still accumulates into dXo_l (>= 3 layers)
             K.attn_bwd(cfg, fp, H_HEADS, kp, dz, act[f"attn{l}"], act[f"qt{l}"], act[f"Xa{l}"],
-                       act[f"Xo{l}"] if Ro > 0 else None, feats.efeat, dqt, dXa_l, dXo_l, G)
+                       act[f"Xo{l}"] if Ro > 0 else None, feats.efeat, dqt, dXa_l, dXo_l, G,
+                       relu_xo=(dXo_l is not None and not more_dXo))
             K.dense_bwd_w(act[f"Xa{l}"], dqt, self.pg(f"gnn{l}.Mcat"), self.pg(f"gnn{l}.cvec"))
             if need_dx:
-                K.dense_fwd(dqt, self.pp(f"gnn{l}.Mcat"), None, dXa_l, accumulate=True, trans_w=True)
-                if dXo_prev is not None and dXo_l is not None:
-                    K.dense_fwd(dXo_prev, self.pp(f"gnn{l}.Wout")[:fp], None, dXo_l, accumulate=True, trans_w=True)
+                K.dense_fwd(dqt, self.pp(f"gnn{l}.Mcat"), None, dXa_l, accumulate=True, trans_w=True, relu_mask=act[f"Xa{l}"])
+                if more_dXo:
+                    K.dense_fwd(dXo_prev, self.pp(f"gnn{l}.Wout")[:fp], None, dXo_l, accumulate=True, trans_w=True,
+                                relu_mask=act[f"Xo{l}"])
             dXa, dXo = dXa_l, dXo_l
         for l, (f, fp, d, kp) in enumerate(self.dims):
             q = lambda nm: self.p(f"gnn{l}.{nm}")

@@ -33,8 +33,8 @@ def _p(t: Optional[torch.Tensor], name="tensor", dtype=torch.float32):
     return N.ptr(t, dtype, name)
 
 
-def dense_fwd(X, W, bias, Y, act: int = 0, accumulate: bool = False, trans_w: bool = False):
-    """Y = act(X @ W + bias)   (trans_w: X @ W.T with W stored [N, K])."""
+def dense_fwd(X, W, bias, Y, act: int = 0, accumulate: bool = False, trans_w: bool = False, relu_mask=None):
+    """Y = act(X @ W + bias)   (trans_w: X @ W.T with W stored [N, K]); relu_mask: Y = where(relu_mask > 0, Y, 0) last."""
     xp, ldx, M, K = _mat(X, "X")
     wp, ldw, wr, wc = _mat(W, "W")
     yp, ldy, My, Ncol = _mat(Y, "Y")
@@ -43,9 +43,14 @@ def dense_fwd(X, W, bias, Y, act: int = 0, accumulate: bool = False, trans_w: bo
         raise ValueError(f"dense_fwd: shape mismatch X{tuple(X.shape)} W{tuple(W.shape)} trans={trans_w} Y{tuple(Y.shape)}")
     if bias is not None:
         N.expect_shape(bias, (Ncol,), "bias")
+    mp, ldm = C.c_void_p(0), 0
+    if relu_mask is not None:
+        mp, ldm, Mm, Nm = _mat(relu_mask, "relu_mask")
+        if (Mm, Nm) != (M, Ncol):
+            raise ValueError(f"dense_fwd: relu_mask {tuple(relu_mask.shape)} does not match Y {tuple(Y.shape)}")
     FLOPS[0] += 2.0 * M * K * Ncol
     rc = N.lib().dgppo_dense_fwd(xp, ldx, wp, ldw, _p(bias, "bias"), yp, ldy, M, K, Ncol, int(act), int(accumulate),
-                                 int(trans_w), N.stream_ptr())
+                                 int(trans_w), mp, ldm, N.stream_ptr())
     N.check(rc, "dgppo_dense_fwd")
 
 
@@ -155,7 +160,7 @@ def attn_fwd(cfg, F, H, Kp, qt, Xa, Xo, efeat, emask, zcat, attn, G):
     N.check(rc, "dgppo_attn_fwd")
 
 
-def attn_bwd(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo, efeat, dqt, dXa, dXo, G):
+def attn_bwd(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo, efeat, dqt, dXa, dXo, G, relu_xo: bool = False):
     n = cfg.n_agents
     N.expect_shape(dzcat, (G * n, Kp), "dzcat")
     N.expect_shape(dqt, (G * n, H * F), "dqt")
@@ -163,7 +168,7 @@ def attn_bwd(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo, efeat, dqt, dXa, dXo, G):
         N.expect_shape(dXa, (G * n, F), "dXa")
     FLOPS[0] += 4.0 * G * n * H * cfg.fan_in * (2 * F + 4)   # dA, dL -> dqt, dXs: twice the forward contractions
     rc = N.lib().dgppo_attn_bwd(C.byref(cfg), F, H, Kp, _p(dzcat), _p(attn), _p(qt), _p(Xa), _p(Xo), _p(efeat), _p(dqt),
-                                _p(dXa), _p(dXo), G, N.stream_ptr())
+                                _p(dXa), _p(dXo), int(relu_xo), G, N.stream_ptr())
     N.check(rc, "dgppo_attn_bwd")
 
 
@@ -232,8 +237,8 @@ def value_loss(v, target, dv, stats):
     N.check(rc, "dgppo_value_loss")
 
 
-def mean_agents(x, y, G, n, D, backward=False):
-    rc = N.lib().dgppo_mean_agents(_p(x), _p(y), G, n, D, int(backward), N.stream_ptr())
+def mean_agents(x, y, G, n, D, backward=False, relu_mask=None):
+    rc = N.lib().dgppo_mean_agents(_p(x), _p(y), G, n, D, int(backward), _p(relu_mask), N.stream_ptr())
     N.check(rc, "dgppo_mean_agents")
 
 

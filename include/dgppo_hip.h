@@ -146,11 +146,13 @@ int32_t dgppo_randn(uint64_t seed, uint64_t offset, float* out, int64_t n_elem, 
 /* All matrices row-major fp32; `ld*` = leading dimension in floats.                              */
 
 /* Y[M,N] = act(X[M,K] W[K,N] + bias) on the fp32 matrix cores; act 0 none / 1 relu; accumulate: Y += ...;
- * trans_w: use W^T (W stored [N,K]) — the input-gradient of a Dense.  Replaces flax nn.Dense as used by
- * dgppo/nn/mlp.py:19-22, dgppo/nn/gnn.py:86-110, dgppo/nn/rnn.py:19-21, algo/module/policy.py:67-70, value.py:41,76. */
+ * trans_w: use W^T (W stored [N,K]) — the input-gradient of a Dense.  relu_mask (optional, [M,N], leading dimension ldm):
+ * Y = (relu_mask > 0) ? result : 0 applied last — the backward of the ReLU whose OUTPUT relu_mask is, fused into the
+ * kernel that finishes that gradient (jax.grad of nn.relu in dgppo/nn/gnn.py:39, mlp.py:29).  Replaces flax nn.Dense as
+ * used by dgppo/nn/mlp.py:19-22, dgppo/nn/gnn.py:86-110, dgppo/nn/rnn.py:19-21, algo/module/policy.py:67-70, value.py:41,76. */
 int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, int32_t ldw, const float* bias, float* Y,
                         int32_t ldy, int32_t M, int32_t K, int32_t N, int32_t act, int32_t accumulate,
-                        int32_t trans_w, void* stream);
+                        int32_t trans_w, const float* relu_mask, int32_t ldm, void* stream);
 /* dW[K,N] += X^T dY ; db[N] += colsum(dY) (db may be NULL): the weight-gradient of a Dense
  * (jax.grad at dgppo/algo/informarl.py:377,440 ; dgppo/algo/dgppo.py:316).                          */
 int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
@@ -185,10 +187,12 @@ int32_t dgppo_graph_feats(const dgppo_env_cfg* cfg, const float* agent, int64_t 
 int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* qt, const float* Xa,
                        const float* Xo, const float* efeat, const float* emask, float* zcat, float* attn, int32_t G,
                        void* stream);
-/* backward of the above: dqt [G*n,H*F]; dXa [G*n,F] / dXo [G*(Ns-n),F] written (not accumulated) when non-NULL.  */
+/* backward of the above: dqt [G*n,H*F]; dXa [G*n,F] / dXo [G*(Ns-n),F] written (not accumulated) when non-NULL.
+ * relu_xo != 0: dXo *= (Xo > 0) — Xo is then the ReLU output of the previous layer's node update, and its gradient
+ * needs no separate pass (dXa still receives the dqt Mcat^T term from dgppo_dense_fwd, which applies the mask).        */
 int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
                        const float* attn, const float* qt, const float* Xa, const float* Xo, const float* efeat,
-                       float* dqt, float* dXa, float* dXo, int32_t G, void* stream);
+                       float* dqt, float* dXa, float* dXo, int32_t relu_xo, int32_t G, void* stream);
 
 /* GraphTransformer parameters (flax Dense_0..4 = q,k,v,e,u; gnn.py:86-110) -> Mcat [Fp,H*Fp], cvec [H*Fp],
  * Wout [Kp,D] used by dgppo_attn_* and the surrounding Denses; and the adjoint map (accumulates into d*).           */
@@ -224,8 +228,10 @@ int32_t dgppo_policy_head(const float* ms, const float* eps, const float* action
 
 /* optax.l2_loss(v, target).mean() (informarl.py:374, dgppo.py:310): dv = (v-target)/count, stats[0] += sum 1/2 d^2 */
 int32_t dgppo_value_loss(const float* v, const float* target, float* dv, float* stats, int32_t count, void* stream);
-/* mean over the n agents of each graph (value.py:33): x [G,n,D] -> y [G,D]; backward: x = dy [G,D] -> y = dx [G,n,D] */
-int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_t D, int32_t backward, void* stream);
+/* mean over the n agents of each graph (value.py:33): x [G,n,D] -> y [G,D]; backward: x = dy [G,D] -> y = dx [G,n,D],
+ * optionally through the ReLU that produced the pooled rows (relu_mask [G,n,D] = that ReLU's output, or NULL)            */
+int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_t D, int32_t backward,
+                          const float* relu_mask, void* stream);
 /* dy *= (y > 0), in place                                                                                             */
 int32_t dgppo_relu_bwd(float* dy, const float* y, int64_t count, void* stream);
 

@@ -533,7 +533,13 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
         dXa = torch.full((R, F), float("nan"), device=cuda)
         dXo = torch.full((G * n_other, F), float("nan"), device=cuda)
         K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo, ef, dq, dXa, dXo, G)
+        # relu_xo: the same call with the ReLU backward of the other nodes' gradient fused in (dXo *= (Xo > 0))
+        dq2, dXa2 = torch.empty_like(dq), torch.empty_like(dXa)
+        dXo2 = torch.full_like(dXo, float("nan"))
+        K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo, ef, dq2, dXa2, dXo2, G, relu_xo=True)
         torch.cuda.synchronize()
+        assert torch.equal(dq2, dq) and torch.equal(dXa2, dXa)
+        assert torch.equal(dXo2, torch.where(Xo > 0, dXo, torch.zeros_like(dXo))), "relu_xo must equal masking afterwards"
         return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo)
 
     families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "valu": {"DGPPO_ATTN_VALU": "1"}}
@@ -595,3 +601,40 @@ def test_attention_wave_kernels_across_topologies(cuda, monkeypatch, kind, n, n_
         for k in ref:
             assert torch.isfinite(got[k]).all(), f"{k} not finite (F={F})"
             _close(got[k], ref[k], 2e-5, f"F={F} {k}")
+
+
+@pytest.mark.parametrize("M,K,N,acc", [(1000, 96, 32, True), (513, 64, 64, False), (70, 24, 8, True)])
+def test_dense_fwd_relu_mask_epilogue(cuda, M, K, N, acc):
+    """dgppo_dense_fwd(relu_mask=...): Y = where(mask > 0, X W^T (+ Y), 0) — the ReLU backward fused into the kernel that
+    finishes a gradient — must equal the unfused result followed by the mask, bit for bit."""
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.randn(M, K, generator=g).to(cuda)
+    W = torch.randn(N, K, generator=g).to(cuda)                   # used transposed: the input-gradient of a Dense
+    mask = torch.randn(M, N, generator=g).to(cuda)
+    mask[::7] = 0.0                                               # exact zeros are masked out (y > 0)
+    Y0 = torch.randn(M, N, generator=g).to(cuda)
+    plain, fused = Y0.clone(), Y0.clone()
+    K_.dense_fwd(X, W, None, plain, accumulate=acc, trans_w=True)
+    K_.dense_fwd(X, W, None, fused, accumulate=acc, trans_w=True, relu_mask=mask)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, torch.where(mask > 0, plain, torch.zeros_like(plain)))
+    # strided mask view (leading dimension != N)
+    wide = torch.randn(M, N + 5, generator=g).to(cuda)
+    fused2 = Y0.clone()
+    K_.dense_fwd(X, W, None, fused2, accumulate=acc, trans_w=True, relu_mask=wide[:, 2:2 + N])
+    assert torch.equal(fused2, torch.where(wide[:, 2:2 + N] > 0, plain, torch.zeros_like(plain)))
+
+
+def test_mean_agents_backward_with_relu_mask(cuda):
+    from dgppo_amd import ops_nn as K_
+    G, n, D = 50, 8, 64
+    g = torch.Generator().manual_seed(4)
+    dy = torch.randn(G, D, generator=g).to(cuda)
+    y = torch.randn(G * n, D, generator=g).to(cuda)
+    a, b = torch.empty(G * n, D, device=cuda), torch.empty(G * n, D, device=cuda)
+    K_.mean_agents(dy, a, G, n, D, backward=True)
+    K_.mean_agents(dy, b, G, n, D, backward=True, relu_mask=y)
+    torch.cuda.synchronize()
+    assert torch.equal(b, torch.where(y > 0, a, torch.zeros_like(a)))
+    assert torch.equal(a.view(G, n, D)[:, 3], dy / n)
