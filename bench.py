@@ -294,6 +294,7 @@ def main():
         "ms_per_step_stats": {"median": float(np.median(sm)), "min": float(sm[0]), "max": float(sm[-1]), "n": len(sm),
                               "note": "rank-0 wall time per iteration (each ends with the host sync of the logged scalars)"},
         "phases_ms_per_step": {k: v / args.steps for k, v in phases.items()},
+        "update_host_ms_last_step": getattr(eng, "host_ms", None),
         "rollout_only_env_steps_per_s_per_gpu": rollout_only,
         "mfma": {"flops_executed_per_step": flops_per_step, "unit": "flop (fp32, 2 per multiply-add, unpadded operand shapes)",
                  "tflops": flops_per_step / (ms_per_step * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,

@@ -67,19 +67,29 @@ class RolloutData:
         self._env_major = False
 
     def finalize(self):
-        """time-major -> env-major copies (pure data movement)."""
+        """time-major -> env-major copies (pure data movement).  The env-major buffers are allocated once per record and
+        rewritten in place afterwards, so that device pointers stay valid for captured HIP graphs of the update."""
         if self._env_major:
             return self
-        tr = lambda x: x.transpose(0, 1).contiguous()
-        self.agent = tr(self.agent_tm)                      # [B, T+1, n, sd]
-        self.hits = tr(self.hits_tm) if self.has_hits else None
-        self.actions = tr(self.action_tm)                   # [B, T, n, 2]
-        self.log_pis = tr(self.log_pi_tm) if self.stochastic else None
-        rnn = tr(self.rnn_tm)                               # [B, T+1, n, 64]
+
+        def tr(name, x):
+            if x is None:
+                return None
+            cur = getattr(self, name, None)
+            want = (x.shape[1], x.shape[0]) + tuple(x.shape[2:])
+            if cur is None or tuple(cur.shape) != want:
+                cur = torch.empty(want, device=x.device, dtype=x.dtype)
+            cur.copy_(x.transpose(0, 1))
+            return cur
+        self.agent = tr("agent", self.agent_tm)                       # [B, T+1, n, sd]
+        self.hits = tr("hits", self.hits_tm) if self.has_hits else None
+        self.actions = tr("actions", self.action_tm)                  # [B, T, n, 2]
+        self.log_pis = tr("log_pis", self.log_pi_tm) if self.stochastic else None
+        self._rnn_em = tr("_rnn_em", self.rnn_tm)                     # [B, T+1, n, 64]
         # stored carry of step t: pre-step (rollout, trainer/utils.py:46-51) or post-step (test_rollout, :71-77)
-        self.rnn_states = rnn[:, :self.T] if self.stochastic else rnn[:, 1:]
-        self.rewards = tr(self.reward_tm)                   # [B, T]
-        self.costs = tr(self.cost_tm)                       # [B, T, n, 2]
+        self.rnn_states = self._rnn_em[:, :self.T] if self.stochastic else self._rnn_em[:, 1:]
+        self.rewards = tr("rewards", self.reward_tm)                  # [B, T]
+        self.costs = tr("costs", self.cost_tm)                        # [B, T, n, 2]
         self._env_major = True
         return self
 
@@ -106,6 +116,7 @@ class Engine:
         self.multi_stream = multi_stream and os.environ.get("DGPPO_MULTI_STREAM", "1") != "0"
         self._side_streams = None
         self._ro_cache: Dict[tuple, dict] = {}
+        self._upd_graph: dict = {}
         self.n_cost = 2
         # ONE flat fp32 buffer [g_policy | g_Vl | g_Vh | scalars]: each network's gradient buffer is a
         # 16-byte-aligned slice of it and the loss/metric sums of the minibatch (stats rows 0..2) sit at its tail, so the
@@ -237,6 +248,10 @@ class Engine:
                       f"continuing with eager launches", flush=True)
         return ro
 
+    def _update_generation(self) -> int:
+        """scratch buffers the minibatch step touches: the engine's arena and every network's"""
+        return self.arena.generation + sum(net.arena.generation for net in self.nets.values())
+
     def _arena_generation(self) -> int:
         """scratch buffers the rollout loop touches live in the engine's arena (features) and the policy's (activations)"""
         return self.arena.generation + self.policy.arena.generation
@@ -279,8 +294,9 @@ class Engine:
         """-> Vl [B,T+1] (or None), Vh [B,T+1,n,nh] of one rollout, with the reference's carry conventions."""
         cfg, T, B = self.cfg, self.T, ro.B
         n, nh, H = cfg.n_agents, self.n_cost, nets.HID
-        Vl_buf = torch.empty(B, T + 1, device=self.device) if want_Vl else None
-        Vh_buf = torch.empty(B, T + 1, n, nh, device=self.device) if want_Vh else None
+        kind = "ro" if ro.stochastic else "det"      # persistent outputs (stable pointers for the captured update graph)
+        Vl_buf = self.arena.get(f"tg.Vl.{kind}", B, T + 1) if want_Vl else None
+        Vh_buf = self.arena.get(f"tg.Vh.{kind}", B, T + 1, n, nh) if want_Vh else None
         block = max(1, min(B, self.prepass_graphs // (T + 1)))
         for e0 in range(0, B, block):
             Eb = min(block, B - e0)
@@ -335,16 +351,19 @@ class Engine:
         Vl, _ = self.values_prepass(ro, want_Vl=True, want_Vh=False)
         fin_agent = ro.agent[:, T].contiguous()
         fin_hits = ro.hits[:, T].contiguous() if ro.has_hits else None
-        fin_cost = torch.empty(B, n, nh, device=dev)
+        A = self.arena
+        fin_cost = A.get("tg.fin_cost", B, n, nh)
         scratch_agent = torch.empty_like(fin_agent)
         OE.env_step(cfg, fin_agent, torch.zeros(B, n, 2, device=dev), ro.goal, ro.obst, fin_hits, self.ray_cos, self.ray_sin,
                     scratch_agent, torch.empty_like(fin_hits) if fin_hits is not None else None, torch.empty(B, device=dev),
                     fin_cost, None)
-        Vh = torch.cat([ro.costs, fin_cost[:, None]], dim=1).contiguous()
-        Qh = torch.empty(B, T, n, nh, device=dev)
-        Ql = torch.empty(B, T, device=dev)
+        Vh = A.get("tg.Vh.crafted", B, T + 1, n, nh)
+        Vh[:, :T].copy_(ro.costs)
+        Vh[:, T].copy_(fin_cost)
+        Qh = A.get("tg.Qh", B, T, n, nh)
+        Ql = A.get("tg.Ql", B, T)
         OA.gae(ro.costs, ro.rewards, Vh, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh, Ql)
-        adv = torch.empty(B, T, n, device=dev)
+        adv = A.get("tg.adv", B, T, n)
         self.stats.zero_()
         OA.advantage(Ql, Vl, Vh, cfg.dt, hp.alpha, hp.cbf_eps, self.cbf_weight_at(step), adv, self.stats[3])
         return dict(Vl=Vl, Vh=Vh, Ql=Ql, Qh=Qh, adv=adv)
@@ -355,13 +374,15 @@ class Engine:
         cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
         n, nh, dev = cfg.n_agents, self.n_cost, self.device
         Vl, _ = self.values_prepass(ro, want_Vl=True, want_Vh=False)
-        Vh = Vl.view(B, T + 1, 1, 1).expand(B, T + 1, n, nh).contiguous()
-        shaped = torch.empty(B, T, device=dev)
+        A = self.arena
+        Vh = A.get("tg.Vh.bcast", B, T + 1, n, nh)
+        Vh.copy_(Vl.view(B, T + 1, 1, 1).expand(B, T + 1, n, nh))
+        shaped = A.get("tg.shaped", B, T)
         OA.shaped_reward(ro.rewards, ro.costs, self.cost_weight_at(step), shaped)
-        Qh = torch.empty(B, T, n, nh, device=dev)
-        Ql = torch.empty(B, T, device=dev)
+        Qh = A.get("tg.Qh", B, T, n, nh)
+        Ql = A.get("tg.Ql", B, T)
         OA.gae(ro.costs, shaped, Vh, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh, Ql)
-        adv = torch.empty(B, T, n, device=dev)
+        adv = A.get("tg.adv", B, T, n)
         self.stats.zero_()
         OA.advantage(Ql, Vl, None, cfg.dt, 0.0, 0.0, 0.0, adv, self.stats[3])
         return dict(Vl=Vl, Ql=Ql, Qh=Qh, adv=adv)
@@ -387,14 +408,14 @@ class Engine:
         n, nh = cfg.n_agents, self.n_cost
         Vl, Vh = self.values_prepass(ro, want_Vl=True)
         _, Vh_det = self.values_prepass(det, want_Vl=False)
-        dev = self.device
-        Qh = torch.empty(B, T, n, nh, device=dev)
-        Ql = torch.empty(B, T, device=dev)
+        A = self.arena
+        Qh = A.get("tg.Qh", B, T, n, nh)
+        Ql = A.get("tg.Ql", B, T)
         OA.gae(ro.costs, ro.rewards, Vh, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh, Ql)
-        Qh_det = torch.empty(B, T, n, nh, device=dev)
-        Ql_det = torch.empty(B, T, device=dev)
+        Qh_det = A.get("tg.Qh_det", B, T, n, nh)
+        Ql_det = A.get("tg.Ql_det", B, T)
         OA.gae(det.costs, det.rewards, Vh_det, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh_det, Ql_det)
-        adv = torch.empty(B, T, n, device=dev)
+        adv = A.get("tg.adv", B, T, n)
         self.stats.zero_()
         OA.advantage(Ql, Vl, Vh, cfg.dt, hp.alpha, hp.cbf_eps, self.cbf_weight_at(step), adv, self.stats[3])
         return dict(Vl=Vl, Vh=Vh, Vh_det=Vh_det, Ql=Ql, Qh=Qh, Qh_det=Qh_det, adv=adv)
@@ -403,6 +424,8 @@ class Engine:
         cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
         n, nh, H = cfg.n_agents, self.n_cost, nets.HID
         informarl = self.algo != "dgppo"          # both baselines train only Vl and the policy
+        import time as _time
+        th = [_time.perf_counter()]                # host-side issue times of the phases (diagnostics: self.host_ms)
         ro.finalize()
         if not informarl:
             det.finalize()
@@ -412,32 +435,45 @@ class Engine:
         C = T // hp.rnn_step
         tg = (self.targets_informarl(ro, step) if self.algo == "informarl" else
               self.targets_hcbfcrpo(ro, step) if self.algo == "hcbfcrpo" else self.targets(ro, det, step))
+        th.append(_time.perf_counter())
         idx_all = torch.from_numpy(np.ascontiguousarray(perm.astype(np.int64))).to(self.device)
         n_mb = B // Eb
         G = Eb * T
         R = G * n
-        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
-        side = self._net_streams() if (self.multi_stream and main is not None) else None
+        is_cuda = self.device.type == "cuda"
         reduce = self.allreduce is not None
-        for mb in range(n_mb):
-            idx = idx_all[mb * Eb:(mb + 1) * Eb]
-            idx32 = idx.to(torch.int32)
+        A = self.arena
+        # static inputs of one minibatch step: the env ids of the minibatch and everything gathered by them
+        mb_idx = A.get("mb.idx", Eb, dtype=torch.int64)
+        mb_idx32 = A.get("mb.idx32", Eb, dtype=torch.int32)
+        Ql_mb = A.get("mb.Ql", Eb, T)
+        act_mb = A.get("mb.act", Eb, T, n, 2)
+        lp_old_mb = A.get("mb.lp_old", Eb, T, n)
+        adv_mb = A.get("mb.adv", Eb, T, n)
+        if not informarl:
+            h0_det = A.get("mb.h0_det", Eb, T, n, H)
+            Qh_det_mb = A.get("mb.Qh_det", Eb, T, n, nh)
+
+        def step_body():
+            """all device work of ONE minibatch (dgppo.py:276-289): gathers, the three forward/backward passes, the
+            exchange and the optimiser steps — reads the minibatch's env ids from mb_idx / mb_idx32."""
+            main = torch.cuda.current_stream(self.device) if is_cuda else None
+            side = self._net_streams() if (self.multi_stream and main is not None) else None
             self.stats[:3].zero_()
-            self._mb = mb
             # everything the three updates read is produced on the main stream first
-            feats = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=idx32)
-            Ql_mb = tg["Ql"].index_select(0, idx)
+            feats = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=mb_idx32)
+            torch.index_select(tg["Ql"], 0, mb_idx, out=Ql_mb)
             if not informarl:
-                feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=idx32)
-                h0_det = det.rnn_states.index_select(0, idx).view(R, H)
-                Qh_det_mb = tg["Qh_det"].index_select(0, idx).view(R, nh)
-            act_mb = ro.actions.index_select(0, idx).view(R, 2)
-            lp_old_mb = ro.log_pis.index_select(0, idx).view(R)
-            adv_mb = tg["adv"].index_select(0, idx).view(R)
+                feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=mb_idx32)
+                torch.index_select(det.rnn_states, 0, mb_idx, out=h0_det)
+                torch.index_select(tg["Qh_det"], 0, mb_idx, out=Qh_det_mb)
+            torch.index_select(ro.actions, 0, mb_idx, out=act_mb)
+            torch.index_select(ro.log_pis, 0, mb_idx, out=lp_old_mb)
+            torch.index_select(tg["adv"], 0, mb_idx, out=adv_mb)
 
             def update_Vl():      # informarl.py:357-385: chunks of rnn_step with zero initial carry
                 act = self.Vl.forward(feats, n_seq=Eb * C, T=hp.rnn_step, h0=None, tag="tr")
-                dv = self.arena.get("mb.dv", G, 1)
+                dv = A.get("mb.dv", G, 1)
                 K.value_loss(act["v"], Ql_mb.view(G, 1), dv, self.stats[0])
                 self.Vl.zero_grads()
                 self.Vl.backward(act, dv)
@@ -445,9 +481,9 @@ class Engine:
                     self._opt_step("Vl", hp.lr_Vl)
 
             def update_Vh():      # dgppo.py:296-321: the deterministic rollout with its stored carry
-                act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det, tag="tr")
-                dvh = self.arena.get("mb.dvh", R, nh)
-                K.value_loss(act["v"], Qh_det_mb, dvh, self.stats[1])
+                act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det.view(R, H), tag="tr")
+                dvh = A.get("mb.dvh", R, nh)
+                K.value_loss(act["v"], Qh_det_mb.view(R, nh), dvh, self.stats[1])
                 self.Vh.zero_grads()
                 self.Vh.backward(act, dvh)
                 if not reduce:
@@ -455,11 +491,11 @@ class Engine:
 
             def update_policy():  # informarl.py:405-457
                 act = self.policy.forward(feats, n_seq=Eb * C * n, T=hp.rnn_step, h0=None, tag="tr")
-                lp = self.arena.get("mb.lp", R)
-                ent = self.arena.get("mb.ent", R)
-                dms = self.arena.get("mb.dms", R, 4)
-                K.policy_head(act["ms"], self.eps_hat, act_mb, None, lp, ent, n, 2, lp_old_mb, adv_mb, dms,
-                              self.stats[2], hp.clip_eps, hp.coef_ent)
+                lp = A.get("mb.lp", R)
+                ent = A.get("mb.ent", R)
+                dms = A.get("mb.dms", R, 4)
+                K.policy_head(act["ms"], self.eps_hat, act_mb.view(R, 2), None, lp, ent, n, 2, lp_old_mb.view(R),
+                              adv_mb.view(R), dms, self.stats[2], hp.clip_eps, hp.coef_ent)
                 self.policy.zero_grads()
                 self.policy.backward(act, dms)
                 if not reduce:
@@ -488,8 +524,54 @@ class Engine:
                 if not informarl:
                     self._opt_step("Vh", hp.lr_Vh)
                 self._opt_step("policy", hp.lr_actor)
+
+        # The minibatch step is ~400 launches of 10-100 us kernels: issuing them from Python costs about as much host time
+        # as they take on the device.  With use_graphs the step is captured once into a HIP graph (all its operands live in
+        # persistent buffers; only mb_idx changes) and replayed for every further minibatch and iteration.  Not with a
+        # gradient hook (a Python callback) or a collective in the step (captured by neither gloo nor the rehearsal path).
+        slot = None
+        if self.use_graphs and is_cuda and self.grad_hook is None and not reduce:
+            key = (self.algo, B, Eb, ro.agent.data_ptr(), det.agent.data_ptr() if det is not None else 0,
+                   tg["adv"].data_ptr(), tg["Ql"].data_ptr(), mb_idx.data_ptr(), self._update_generation())
+            slot = self._upd_graph
+            if slot.get("key") != key:
+                slot.clear()
+                slot["key"] = key
+        for mb in range(n_mb):
+            self._mb = mb
+            mb_idx.copy_(idx_all[mb * Eb:(mb + 1) * Eb])
+            mb_idx32.copy_(mb_idx)
+            if slot is not None and slot.get("graph") is not None:
+                slot["graph"].replay()
+                K.FLOPS[0] += slot["flops"]
+                continue
+            f0 = K.FLOPS[0]
+            step_body()
+            if slot is not None and not slot.get("failed", False):
+                slot["flops"] = K.FLOPS[0] - f0
+                if slot.get("key")[-1] != self._update_generation():      # the eager pass grew a scratch buffer: try again later
+                    slot["key"] = slot["key"][:-1] + (self._update_generation(),)
+                    continue
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    f1 = K.FLOPS[0]
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        step_body()
+                    K.FLOPS[0] = f1
+                    slot["graph"] = graph
+                except Exception as ex:                             # keep training: eager launches are always correct
+                    slot["failed"] = True
+                    torch.cuda.synchronize()
+                    print(f"[dgppo_amd] HIP-graph capture of the minibatch step failed ({type(ex).__name__}: {ex}); "
+                          f"continuing with eager launches", flush=True)
+        th.append(_time.perf_counter())
         self._last = dict(Ql_mb=Ql_mb, G=G, R=R, nh=nh, B=B)
-        return self.info(ro)
+        out = self.info(ro)
+        th.append(_time.perf_counter())
+        # host time spent ISSUING finalize + targets, then the minibatch loop, then waiting for the device in info()
+        self.host_ms = {"issue_targets": 1e3 * (th[1] - th[0]), "issue_minibatches": 1e3 * (th[2] - th[1]),
+                        "wait_device": 1e3 * (th[3] - th[2])}
+        return out
 
     def info(self, ro: RolloutData) -> dict:
         """scalars of the LAST minibatch (dgppo.py:292) with the reference's key names; one host sync."""

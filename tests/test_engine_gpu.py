@@ -418,3 +418,35 @@ def test_two_rank_update_allreduce_equals_full_minibatch(cuda, tmp_path):
     # compare the FIRST step's logged quantities through a one-minibatch single-process run is not possible after two
     # optimiser steps, so the loss check is on the replicas' agreement above and on finiteness here
     assert all(np.isfinite(v) for v in res[0]["info"].values())
+
+
+@pytest.mark.parametrize("algo", ["dgppo", "informarl"])
+def test_update_hip_graph_replay_equals_eager(cuda, algo):
+    """Engine(use_graphs=True) captures ONE minibatch step (gathers, three forward/backward passes on three streams, clip +
+    Adam) into a HIP graph during the first update and replays it for every later minibatch and iteration.  Over three
+    iterations (the first captures, the others replay throughout, with fresh rollouts in the same persistent buffers)
+    the parameters and the logged scalars must follow the eager engine's."""
+    from dgppo_amd import engine as EN
+    B, T_, rs, bs = 8, 8, 4, 16
+    cfg, ocfg, hp, eng_e, trees = _setup("LidarSpread", 3, 2, B, T_, cuda, bs, rs, multi_stream=True, algo=algo)
+    eng_g = EN.Engine(cfg, hp, cuda, T=T_, use_graphs=True, multi_stream=True, algo=algo)
+    for k, net in eng_g.nets.items():
+        net.load_tree(trees[k])
+    eng_g.set_entropy_noise(77)
+    for it in range(3):
+        seeds = (torch.arange(1, B + 1, dtype=torch.int64, device=cuda) + 50 * it) * 7919
+        perm = np.random.default_rng(it).permutation(B)
+        infos = []
+        for eng in (eng_e, eng_g):
+            ro = eng.rollout(seeds, True, noise_seed=3 + it)
+            det = eng.rollout(seeds + 1000, False) if algo == "dgppo" else None
+            infos.append(eng.update(ro, det, it, perm))
+            torch.cuda.synchronize()
+        for name in eng_e.nets:
+            pa, pb = eng_e.nets[name].params, eng_g.nets[name].params
+            err = float((pa - pb).abs().max())
+            assert err <= 1e-6 * max(1.0, float(pa.abs().max())), f"iteration {it}, {name}: graph replay drifted by {err:.3e}"
+            assert float(eng_e.opt[name].state[2]) == float(eng_g.opt[name].state[2]) == (it + 1) * (B // (bs // T_))
+        for k in infos[0]:
+            assert abs(infos[0][k] - infos[1][k]) <= 1e-5 * max(1.0, abs(infos[0][k])), (it, k)
+    assert eng_g._upd_graph.get("graph") is not None, "the minibatch step was never captured"
