@@ -1,7 +1,7 @@
 """dgppo.algo equivalent (dgppo/algo/__init__.py:8-18)."""
 from .base import Algorithm
 from .dgppo import DGPPO
-from .informarl import HCBFCRPO, InforMARL
+from .informarl import HCBFCRPO, InforMARL, InforMARLLagr
 
 
 def make_algo(algo: str, **kwargs) -> Algorithm:
@@ -12,6 +12,5 @@ def make_algo(algo: str, **kwargs) -> Algorithm:
     if algo == "hcbfcrpo":
         return HCBFCRPO(**kwargs)
     if algo == "informarl_lagr":
-        raise NotImplementedError(f"algo '{algo}' is a baseline of the reference outside the scope of this build "
-                                  f"(SURVEY §2 rows 18-19, §8f rank 3); available: 'dgppo', 'informarl', 'hcbfcrpo'")
+        return InforMARLLagr(**kwargs)
     raise ValueError(f"Unknown algorithm: {algo}")

@@ -124,3 +124,63 @@ class HCBFCRPO(InforMARL):
     @property
     def config(self) -> dict:          # the DGPPO config keys (hcbfcrpo.py inherits dgppo.py's property)
         return DGPPO.config.fget(self)
+
+
+class InforMARLLagr(InforMARL):
+    """InforMARL with a learned constraint value and Lagrange multipliers (dgppo/algo/informarl_lagr.py:25-327): the
+    constraint-value net is DecRStateFn(use_global_info=True) with its own zero-initialised recurrent carry, trained on
+    the stochastic rollout in chunks of rnn_step; advantage = -Al - mean_h(Ah * lambda[a,h]); after every policy step the
+    multipliers move by lr_lagr along mean(Vh (1 - gamma) + rho Ah) and are clipped at zero."""
+
+    def __init__(self, env, node_dim: int, edge_dim: int, state_dim: int, action_dim: int, n_agents: int,
+                 actor_gnn_layers: int = 2, Vl_gnn_layers: int = 2, Vh_gnn_layers: int = 1, gamma: float = 0.99,
+                 lr_actor: float = 3e-4, lr_Vl: float = 1e-3, lr_Vh: float = 1e-3, batch_size: int = 8192,
+                 epoch_ppo: int = 1, clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2,
+                 max_grad_norm: float = 2.0, seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16,
+                 use_lstm: bool = False, lagr_init: float = 0.78, lr_lagr: float = 1e-7, train_steps: int = 1e5,
+                 allreduce=None, world: int = 1, **kwargs):
+        Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
+        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
+            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1")
+        if allreduce is not None:
+            raise NotImplementedError("informarl_lagr runs on one device in this build (the multiplier update is not sharded)")
+        assert node_dim == env.node_dim and action_dim == 2
+        self.state_dim, self.seed = state_dim, seed
+        self.epoch_ppo, self.use_rnn, self.rnn_layers, self.use_lstm = epoch_ppo, use_rnn, rnn_layers, use_lstm
+        self.hp = EN.Hyper(gamma=gamma, gae_lambda=gae_lambda, clip_eps=clip_eps, coef_ent=coef_ent,
+                           max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
+                           rnn_step=rnn_step, train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers,
+                           Vl_gnn_layers=Vl_gnn_layers, Vh_gnn_layers=Vh_gnn_layers, lagr_init=lagr_init, lr_lagr=lr_lagr)
+        self.device = env.device
+        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, use_graphs=True, multi_stream=True,
+                                algo="informarl_lagr")
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
+        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3, global_info=True))
+        self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self.init_Vh_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self._rng = np.random.default_rng([seed, 99])
+        self._single = nets.Arena(self.device)
+
+    @property
+    def ah_lagr(self):
+        return self.engine.lagr
+
+    @property
+    def config(self) -> dict:          # informarl_lagr.py:109-116
+        hp = self.hp
+        return dict(InforMARL.config.fget(self), lr_Vh=hp.lr_Vh, Vh_gnn_layers=hp.Vh_gnn_layers, lagr_init=hp.lagr_init,
+                    lr_lagr=hp.lr_lagr)
+
+    @property
+    def params(self):
+        e = self.engine
+        return {"policy": e.policy.to_tree(), "Vl": e.Vl.to_tree(), "Vh": e.Vh.to_tree()}
+
+    # checkpoints: {dir}/{step}/{actor,Vl,Vh}.pkl (informarl_lagr.py:311-327)
+    def save(self, save_dir: str, step: int):
+        DGPPO.save(self, save_dir, step)
+
+    def load(self, load_dir: str, step: int):
+        DGPPO.load(self, load_dir, step)

@@ -285,3 +285,134 @@ extern "C" int32_t dgppo_shaped_reward(const float* reward, const float* cost, f
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
+
+// =====================================================================================================================
+// InforMARL-Lagrangian (dgppo/algo/informarl_lagr.py): advantage with the per-(agent, component) multipliers and the
+// multiplier update.
+// =====================================================================================================================
+struct AdvLagrArgs {
+  const float* Ql; const float* Vl; const float* Qh; const float* Vh; const float* lagr;
+  float* adv;       // [B,T,n]
+  float* Ah;        // [B,T,n,nh] normalised constraint advantage (update_lagr reads it again)
+  int B, T, n, nh;
+};
+
+// informarl_lagr.py:219-235: Al = (Ql - Vl) standardised per env over T, negated; Ah = (Qh - Vh) standardised per
+// (env, agent, component) over T; A = -Al - mean_h(Ah * lagr[a, h]).  One workgroup per env; population std, + 1e-8.
+__global__ void __launch_bounds__(256) adv_lagr_kernel(AdvLagrArgs a) {
+  __shared__ float red[256];
+  __shared__ float s_mean[1 + 64], s_den[1 + 64];
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int T = a.T, n = a.n, nh = a.nh, AH = n * nh;
+  const float* Ql = a.Ql + (size_t)b * T;
+  const float* Vl = a.Vl + (size_t)b * (T + 1);
+  const float* Qh = a.Qh + (size_t)b * T * AH;
+  const float* Vh = a.Vh + (size_t)b * (T + 1) * AH;
+  // series 0: Ql - Vl ; series 1 + c: Qh - Vh of column c = agent * nh + h
+  for (int s0 = 0; s0 < 1 + AH; ++s0) {
+    float acc = 0.0f;
+    for (int t = tid; t < T; t += nt) acc += (s0 == 0) ? (Ql[t] - Vl[t]) : (Qh[(size_t)t * AH + s0 - 1] - Vh[(size_t)t * AH + s0 - 1]);
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = nt / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float mean = red[0] / (float)T;
+    __syncthreads();
+    acc = 0.0f;
+    for (int t = tid; t < T; t += nt) {
+      const float d = ((s0 == 0) ? (Ql[t] - Vl[t]) : (Qh[(size_t)t * AH + s0 - 1] - Vh[(size_t)t * AH + s0 - 1])) - mean;
+      acc += d * d;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = nt / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) { s_mean[s0] = mean; s_den[s0] = sqrtf(red[0] / (float)T) + 1e-8f; }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < T * n; idx += nt) {
+    const int t = idx / n, ag = idx - t * n;
+    const float al = -(((Ql[t] - Vl[t]) - s_mean[0]) / s_den[0]);
+    float acc = 0.0f;
+    for (int h = 0; h < nh; ++h) {
+      const int c = ag * nh + h;
+      const float ah = ((Qh[(size_t)t * AH + c] - Vh[(size_t)t * AH + c]) - s_mean[1 + c]) / s_den[1 + c];
+      a.Ah[((size_t)b * T + t) * AH + c] = ah;
+      acc += ah * a.lagr[c];
+    }
+    a.adv[(size_t)b * T * n + idx] = al - acc / (float)nh;
+  }
+}
+
+extern "C" int32_t dgppo_advantage_lagr(const float* Ql, const float* Vl, const float* Qh, const float* Vh,
+                                        const float* lagr, float* adv, float* Ah, int32_t B, int32_t T, int32_t n,
+                                        int32_t nh, void* stream) {
+  DGPPO_REQUIRE(B >= 0 && T >= 1 && n >= 1 && nh >= 1 && n * nh <= 64, "advantage_lagr: bad sizes (n * nh <= 64)");
+  if (B == 0) return 0;
+  DGPPO_REQUIRE(Ql && Vl && Qh && Vh && lagr && adv && Ah, "advantage_lagr: NULL operand");
+  AdvLagrArgs a{Ql, Vl, Qh, Vh, lagr, adv, Ah, B, T, n, nh};
+  hipLaunchKernelGGL(adv_lagr_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// update_lagr (informarl_lagr.py:286-309): delta[a,h] = -mean_{b,t}( Vh (1 - gamma) + exp(log_pi_new - log_pi_old) Ah ),
+// lagr = relu(lagr - delta * lr).  rows = b*T*n entries, agent = row % n; Vh is addressed with its own env stride
+// (it is the [B, T+1, n, nh] value array, of which the first T steps of each env are used).
+__global__ void __launch_bounds__(256) lagr_sum_kernel(const float* __restrict__ lp_new, const float* __restrict__ lp_old,
+                                                       const float* __restrict__ Vh, const float* __restrict__ Ah,
+                                                       float* __restrict__ sums, long rows, int n, int nh, int T,
+                                                       long vh_env_stride, float one_minus_gamma) {
+  extern __shared__ float s_acc[];   // [n * nh]
+  for (int c = threadIdx.x; c < n * nh; c += blockDim.x) s_acc[c] = 0.0f;
+  __syncthreads();
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+    const int ag = (int)(r % n);
+    const long bt = r / n, e = bt / T, t = bt - e * T;
+    const float ratio = expf(lp_new[r] - lp_old[r]);
+    for (int h = 0; h < nh; ++h) {
+      const float vh = Vh[e * vh_env_stride + (t * n + ag) * nh + h];
+      atomicAdd(&s_acc[ag * nh + h], vh * one_minus_gamma + ratio * Ah[r * nh + h]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n * nh; c += blockDim.x) atomicAdd(&sums[c], s_acc[c]);
+}
+
+__global__ void lagr_apply_kernel(float* __restrict__ lagr, float* __restrict__ sums, int count, float inv_bt, float lr) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= count) return;
+  const float delta = -(sums[c] * inv_bt);
+  lagr[c] = fmaxf(lagr[c] - delta * lr, 0.0f);
+  sums[c] = 0.0f;                        // ready for the next minibatch
+}
+
+extern "C" int32_t dgppo_lagr_update(const float* lp_new, const float* lp_old, const float* Vh, int64_t vh_env_stride,
+                                     const float* Ah, float* lagr, float* sums, int32_t n_env, int32_t T, int32_t n,
+                                     int32_t nh, float one_minus_gamma, float lr, void* stream) {
+  DGPPO_REQUIRE(n_env >= 1 && T >= 1 && n >= 1 && nh >= 1 && n * nh <= 1024, "lagr_update: bad sizes");
+  DGPPO_REQUIRE(lp_new && lp_old && Vh && Ah && lagr && sums, "lagr_update: NULL operand");
+  const long rows = (long)n_env * T * n;
+  const int grid = (int)((rows + 255) / 256 < 512 ? (rows + 255) / 256 : 512);
+  hipLaunchKernelGGL(lagr_sum_kernel, dim3(grid), dim3(256), sizeof(float) * n * nh, (hipStream_t)stream, lp_new, lp_old, Vh,
+                     Ah, sums, rows, n, nh, T, (long)vh_env_stride, one_minus_gamma);
+  hipLaunchKernelGGL(lagr_apply_kernel, dim3((n * nh + 63) / 64), dim3(64), 0, (hipStream_t)stream, lagr, sums, n * nh,
+                     1.0f / (float)((long)n_env * T), lr);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// out = max(x, 0) elementwise: the clipped costs fed to the Dec-OCP GAE by the Lagrangian baseline
+// (jnp.clip(rollout.costs, a_min=0), informarl_lagr.py:213)
+__global__ void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, long count) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = fmaxf(x[i], 0.0f);
+}
+
+extern "C" int32_t dgppo_relu_fwd(const float* x, float* out, int64_t count, void* stream) {
+  DGPPO_REQUIRE(count >= 0, "relu_fwd: count < 0");
+  if (count == 0) return 0;
+  DGPPO_REQUIRE(x && out, "relu_fwd: NULL operand");
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (long)count);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}

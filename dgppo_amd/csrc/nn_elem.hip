@@ -679,7 +679,9 @@ __global__ void mean_agents_kernel(const float* __restrict__ x, float* __restric
   if (backward) {  // x = dP [G, D] -> y = dX [G, n, D]  (optionally through the ReLU whose output is relu_mask)
     if (idx >= G * n * D) return;
     const int d = idx % D, g = idx / (n * D);
-    const float v = x[(size_t)g * D + d] / (float)n;
+    // backward == 1: y = x / n (gradient of the mean);  backward == 2: y += x (broadcast-add of a per-graph row: the
+    // tiled global feature of DecRStateFn(use_global_info=True), value.py:66-68, whose mean factor is already in x)
+    const float v = (backward == 2) ? y[idx] + x[(size_t)g * D + d] : x[(size_t)g * D + d] / (float)n;
     y[idx] = (relu_mask == nullptr || relu_mask[idx] > 0.0f) ? v : 0.0f;
   } else {
     if (idx >= G * D) return;
@@ -693,6 +695,7 @@ __global__ void mean_agents_kernel(const float* __restrict__ x, float* __restric
 extern "C" int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_t D, int32_t backward,
                                      const float* relu_mask, void* stream) {
   DGPPO_REQUIRE(G >= 0 && n >= 1 && D >= 1, "mean_agents: bad sizes");
+  DGPPO_REQUIRE(backward >= 0 && backward <= 2, "mean_agents: backward must be 0, 1 or 2");
   if (G == 0) return 0;
   DGPPO_REQUIRE(x && y, "mean_agents: NULL operand");
   const long total = backward ? (long)G * n * D : (long)G * D;

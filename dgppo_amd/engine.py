@@ -43,6 +43,8 @@ class Hyper:
     actor_gnn_layers: int = 2
     Vl_gnn_layers: int = 2
     Vh_gnn_layers: int = 1
+    lagr_init: float = 0.78           # InforMARL-Lagrangian: initial multipliers, their step size (informarl_lagr.py:52-53)
+    lr_lagr: float = 1e-7
     cost_weight: float = 0.0          # InforMARL: weight of sum(max(cost, 0)) in the stage cost (informarl.py:329)
     cost_schedule: bool = False       # InforMARL: x5 at 50 % and again x5 at 75 % of train_steps (informarl.py:189-198)
 
@@ -106,8 +108,10 @@ class Engine:
                  allreduce: Optional[Callable[[torch.Tensor], None]] = None, world: int = 1, prepass_graphs: int = 1 << 16,
                  use_graphs: bool = False, multi_stream: bool = False, algo: str = "dgppo"):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
-        assert algo in ("dgppo", "informarl", "hcbfcrpo"), algo
-        # "informarl" / "hcbfcrpo": no constraint-value network and no deterministic rollout (informarl.py, hcbfcrpo.py)
+        assert algo in ("dgppo", "informarl", "hcbfcrpo", "informarl_lagr"), algo
+        # "informarl" / "hcbfcrpo": no constraint-value network and no deterministic rollout (informarl.py, hcbfcrpo.py);
+        # "informarl_lagr": a constraint-value network with global information and its own recurrent carry, trained on the
+        # stochastic rollout, plus per-(agent, component) Lagrange multipliers (informarl_lagr.py)
         self.algo = algo
         # HIP-graph replay of the launch-bound rollout loop (18 small kernels per env step).  Opt-in because the record
         # buffers then belong to the engine: a RolloutData stays valid only until the next rollout of the same kind.
@@ -122,10 +126,12 @@ class Engine:
         # 16-byte-aligned slice of it and the loss/metric sums of the minibatch (stats rows 0..2) sit at its tail, so the
         # data-parallel update needs a single all-reduce per minibatch.  Row 3 of the stats (the per-iteration safe count)
         # lies outside the reduced range.
-        spec = [("policy", hyper.actor_gnn_layers, 2), ("Vl", hyper.Vl_gnn_layers, 1)]
+        spec = [("policy", "policy", hyper.actor_gnn_layers, 2), ("Vl", "Vl", hyper.Vl_gnn_layers, 1)]
         if algo == "dgppo":
-            spec.append(("Vh", hyper.Vh_gnn_layers, self.n_cost))
-        sizes = [nets.make_layout(k, cfg.node_dim, layers, n_out).size for k, layers, n_out in spec]
+            spec.append(("Vh", "Vh", hyper.Vh_gnn_layers, self.n_cost))
+        elif algo == "informarl_lagr":
+            spec.append(("Vh", "Vhg", hyper.Vh_gnn_layers, self.n_cost))
+        sizes = [nets.make_layout(kind, cfg.node_dim, layers, n_out).size for _, kind, layers, n_out in spec]
         offs, tot = [], 0
         for sz in sizes:
             offs.append(tot)
@@ -133,8 +139,11 @@ class Engine:
         self.flat_grads = torch.zeros(tot + 4 * 8, device=device)
         self.n_reduced = tot + 3 * 8
         self.stats = self.flat_grads[tot:tot + 32].view(4, 8)
-        built = {k: nets.Net(k, cfg, layers, n_out, device, grads=self.flat_grads[o:o + sz])
-                 for (k, layers, n_out), o, sz in zip(spec, offs, sizes)}
+        built = {k: nets.Net(kind, cfg, layers, n_out, device, grads=self.flat_grads[o:o + sz])
+                 for (k, kind, layers, n_out), o, sz in zip(spec, offs, sizes)}
+        if algo == "informarl_lagr":
+            self.lagr = torch.full((cfg.n_agents, self.n_cost), float(hyper.lagr_init), device=device)   # informarl_lagr.py:107
+            self.lagr_sums = torch.zeros(cfg.n_agents * self.n_cost, device=device)
         self.policy, self.Vl, self.Vh = built["policy"], built["Vl"], built.get("Vh")
         self.opt = {k: OptState(net.layout.size, device) for k, net in self.nets.items()}
         self.arena = nets.Arena(device)
@@ -387,6 +396,30 @@ class Engine:
         OA.advantage(Ql, Vl, None, cfg.dt, 0.0, 0.0, 0.0, adv, self.stats[3])
         return dict(Vl=Vl, Ql=Ql, Qh=Qh, adv=adv)
 
+    def targets_lagr(self, ro: RolloutData, step: int):
+        """InforMARL-Lagrangian (informarl_lagr.py:177-235): Vl and Vh scans (each with its own zero-initialised carry, final
+        value on next_graph[-1] = one more scan step), Dec-OCP GAE on the clipped costs, advantage with the multipliers."""
+        cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
+        n, nh, A = cfg.n_agents, self.n_cost, self.arena
+        Vl, _ = self.values_prepass(ro, want_Vl=True, want_Vh=False)
+        Vh = A.get("tg.Vh.lagr", B, T + 1, n, nh)
+        block = max(1, min(B, self.prepass_graphs // (T + 1)))
+        for e0 in range(0, B, block):
+            Eb = min(block, B - e0)
+            feats = self._block_feats("pre", ro, e0, Eb, 0, T + 1)
+            act = self.Vh.forward(feats, n_seq=Eb * n, T=T + 1, h0=None, tag="pre", train=False)
+            Vh[e0:e0 + Eb].copy_(act["v"].view(Eb, T + 1, n, nh))
+        cpos = A.get("tg.costs_pos", B, T, n, nh)
+        OA.relu_fwd(ro.costs, cpos)                                  # jnp.clip(rollout.costs, a_min=0)
+        Qh = A.get("tg.Qh", B, T, n, nh)
+        Ql = A.get("tg.Ql", B, T)
+        OA.gae(cpos, ro.rewards, Vh, Vl, self.lam_pow, hp.gamma, hp.gae_lambda, Qh, Ql)
+        adv = A.get("tg.adv", B, T, n)
+        Ah = A.get("tg.Ah", B, T, n, nh)
+        self.stats.zero_()
+        OA.advantage_lagr(Ql, Vl, Qh, Vh, self.lagr, adv, Ah)
+        return dict(Vl=Vl, Vh=Vh, Ql=Ql, Qh=Qh, adv=adv, Ah=Ah)
+
     def _net_streams(self):
         if self._side_streams is None:
             self._side_streams = [torch.cuda.Stream(self.device) for _ in range(3)]
@@ -423,18 +456,21 @@ class Engine:
     def update(self, ro: RolloutData, det: RolloutData, step: int, perm: np.ndarray) -> dict:
         cfg, T, B, hp = self.cfg, self.T, ro.B, self.hp
         n, nh, H = cfg.n_agents, self.n_cost, nets.HID
-        informarl = self.algo != "dgppo"          # both baselines train only Vl and the policy
+        informarl = self.algo in ("informarl", "hcbfcrpo")          # these baselines train only Vl and the policy
+        lagr = self.algo == "informarl_lagr"
+        assert not (lagr and self.allreduce is not None), "informarl_lagr is single-device in this build"
         import time as _time
         th = [_time.perf_counter()]                # host-side issue times of the phases (diagnostics: self.host_ms)
         ro.finalize()
-        if not informarl:
+        if self.algo == "dgppo":
             det.finalize()
         assert B * T >= hp.batch_size, "n_env_train * T must be >= batch_size (dgppo.py:153)"
         Eb = hp.batch_size // T
         assert B % Eb == 0 and T % hp.rnn_step == 0, "B % (batch_size // T) == 0 and T % rnn_step == 0 required (SURVEY A.11)"
         C = T // hp.rnn_step
         tg = (self.targets_informarl(ro, step) if self.algo == "informarl" else
-              self.targets_hcbfcrpo(ro, step) if self.algo == "hcbfcrpo" else self.targets(ro, det, step))
+              self.targets_hcbfcrpo(ro, step) if self.algo == "hcbfcrpo" else
+              self.targets_lagr(ro, step) if lagr else self.targets(ro, det, step))
         th.append(_time.perf_counter())
         idx_all = torch.from_numpy(np.ascontiguousarray(perm.astype(np.int64))).to(self.device)
         n_mb = B // Eb
@@ -450,9 +486,13 @@ class Engine:
         act_mb = A.get("mb.act", Eb, T, n, 2)
         lp_old_mb = A.get("mb.lp_old", Eb, T, n)
         adv_mb = A.get("mb.adv", Eb, T, n)
-        if not informarl:
+        if self.algo == "dgppo":
             h0_det = A.get("mb.h0_det", Eb, T, n, H)
             Qh_det_mb = A.get("mb.Qh_det", Eb, T, n, nh)
+        if lagr:
+            Qh_mb = A.get("mb.Qh", Eb, T, n, nh)
+            Vh_mb = A.get("mb.Vh", Eb, T + 1, n, nh)
+            Ah_mb = A.get("mb.Ah", Eb, T, n, nh)
 
         def step_body():
             """all device work of ONE minibatch (dgppo.py:276-289): gathers, the three forward/backward passes, the
@@ -463,10 +503,14 @@ class Engine:
             # everything the three updates read is produced on the main stream first
             feats = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=mb_idx32)
             torch.index_select(tg["Ql"], 0, mb_idx, out=Ql_mb)
-            if not informarl:
+            if self.algo == "dgppo":
                 feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=mb_idx32)
                 torch.index_select(det.rnn_states, 0, mb_idx, out=h0_det)
                 torch.index_select(tg["Qh_det"], 0, mb_idx, out=Qh_det_mb)
+            if lagr:
+                torch.index_select(tg["Qh"], 0, mb_idx, out=Qh_mb)
+                torch.index_select(tg["Vh"], 0, mb_idx, out=Vh_mb)
+                torch.index_select(tg["Ah"], 0, mb_idx, out=Ah_mb)
             torch.index_select(ro.actions, 0, mb_idx, out=act_mb)
             torch.index_select(ro.log_pis, 0, mb_idx, out=lp_old_mb)
             torch.index_select(tg["adv"], 0, mb_idx, out=adv_mb)
@@ -480,10 +524,15 @@ class Engine:
                 if not reduce:
                     self._opt_step("Vl", hp.lr_Vl)
 
-            def update_Vh():      # dgppo.py:296-321: the deterministic rollout with its stored carry
-                act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det.view(R, H), tag="tr")
+            def update_Vh():
+                if lagr:          # informarl_lagr.py:252-284: chunks of rnn_step, zero initial carry, stochastic rollout
+                    act = self.Vh.forward(feats, n_seq=Eb * C * n, T=hp.rnn_step, h0=None, tag="tr")
+                    target = Qh_mb
+                else:             # dgppo.py:296-321: the deterministic rollout with its stored carry
+                    act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det.view(R, H), tag="tr")
+                    target = Qh_det_mb
                 dvh = A.get("mb.dvh", R, nh)
-                K.value_loss(act["v"], Qh_det_mb.view(R, nh), dvh, self.stats[1])
+                K.value_loss(act["v"], target.view(R, nh), dvh, self.stats[1])
                 self.Vh.zero_grads()
                 self.Vh.backward(act, dvh)
                 if not reduce:
@@ -500,6 +549,11 @@ class Engine:
                 self.policy.backward(act, dms)
                 if not reduce:
                     self._opt_step("policy", hp.lr_actor)
+                if lagr:          # update_lagr (informarl_lagr.py:286-309) with the UPDATED policy: log pi of the stored actions
+                    full = self.policy.forward(feats, n_seq=Eb * n, T=T, h0=None, tag="lg", train=False)   # whole episodes, zero carry
+                    lp_full = A.get("mb.lp_full", R)
+                    K.policy_head(full["ms"], self.eps_hat, act_mb.view(R, 2), None, lp_full, A.get("mb.ent_full", R), n, 2)
+                    OA.lagr_update(lp_full.view(Eb, T, n), lp_old_mb, Vh_mb, Ah_mb, self.lagr, self.lagr_sums, hp.gamma, hp.lr_lagr)
 
             if informarl:
                 update_Vh = lambda: None                       # noqa: E731  (no constraint-value network)
@@ -565,7 +619,7 @@ class Engine:
                     print(f"[dgppo_amd] HIP-graph capture of the minibatch step failed ({type(ex).__name__}: {ex}); "
                           f"continuing with eager launches", flush=True)
         th.append(_time.perf_counter())
-        self._last = dict(Ql_mb=Ql_mb, G=G, R=R, nh=nh, B=B)
+        self._last = dict(Ql_mb=Ql_mb, G=G, R=R, nh=nh, B=B, Qh_mb=Qh_mb if lagr else None)
         out = self.info(ro)
         th.append(_time.perf_counter())
         # host time spent ISSUING finalize + targets, then the minibatch loop, then waiting for the device in info()
@@ -588,9 +642,13 @@ class Engine:
             "policy/log_pi_min": float(ro.log_pis.min()), "policy/clip_frac": float(s[2, 2] / R),
             "policy/entropy": float(s[2, 1] / R), "policy/total_variation_dist": float(0.5 * s[2, 3] / R),
         }
+        if self.algo == "informarl_lagr":   # informarl_lagr.py:278-282,309
+            out.update({"Vh/loss": float(s[1, 0] / (R * nh)), "Vh/grad_norm": float(o["Vh"][4]), "Vh/has_nan": float(o["Vh"][5]),
+                        "Vh/max_target": float(L["Qh_mb"].max()), "Vh/min_target": float(L["Qh_mb"].min()),
+                        "policy/lagr_mean": float(self.lagr.mean())})
         if self.algo == "dgppo":       # InforMARL logs only the Vl and policy keys (informarl.py:357-457)
             out.update({"Vh/loss_Vh": float(s[1, 0] / (R * nh)), "Vh/grad_Vh_norm": float(o["Vh"][4]),
                         "Vh/grad_Vh_has_nan": float(o["Vh"][5])})
-        if self.algo != "informarl":   # hcbfcrpo.py:204
+        if self.algo in ("dgppo", "hcbfcrpo"):   # hcbfcrpo.py:204
             out["eval/safe_data"] = float(s[3, 0] / (B * self.T * self.cfg.n_agents))
         return out

@@ -46,10 +46,10 @@ def _gnn(rng, node_dim, n_layers, msg_dim=32, out_dim=64, n_heads=3):
     return p
 
 
-def _mlp(rng):
+def _mlp(rng, f_in: int = 64):
     p = {}
     for i in range(2):
-        p[f"Dense_{i}"] = _dense(rng, 64, 64)
+        p[f"Dense_{i}"] = _dense(rng, f_in if i == 0 else 64, 64)
         p[f"LayerNorm_{i}"] = {"scale": np.ones(64, np.float32), "bias": np.zeros(64, np.float32)}
     return p
 
@@ -71,7 +71,8 @@ def init_policy(seed: int, node_dim: int, action_dim: int, gnn_layers: int) -> d
         "OutputDenseStdTrans": _dense(rng, 64, action_dim)}}
 
 
-def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, stream: int) -> dict:
+def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, stream: int, global_info: bool = False) -> dict:
+    """global_info: DecRStateFn(use_global_info=True) — the head's first Dense takes [x_i | mean_j x_j] (value.py:66-68)"""
     rng = np.random.default_rng([seed, stream])
-    return {"params": {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "ValueGNNHead": _mlp(rng),
+    return {"params": {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "ValueGNNHead": _mlp(rng, 128 if global_info else 64),
                        "RNN_0": {"GRUCell_1": _gru(rng)}, "Dense_0": _dense(rng, 64, n_out)}}

@@ -42,7 +42,8 @@ class Layout:
 
 
 def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int) -> Layout:
-    """kind: 'policy' | 'Vl' | 'Vh'.  Dense kernels are [in, out] like flax."""
+    """kind: 'policy' | 'Vl' | 'Vh' | 'Vhg' (= DecRStateFn(use_global_info=True): the head sees [x_i | mean_j x_j],
+    value.py:66-68, so its first Dense is 128 wide).  Dense kernels are [in, out] like flax."""
     L = Layout()
     f = node_dim
     for l in range(gnn_layers):
@@ -53,7 +54,7 @@ def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int) -> Layout
             L.add(f"gnn{l}.{nm}", *shp)
         f = d
     for i in (1, 2):
-        L.add(f"mlp.W{i}", HID, HID)
+        L.add(f"mlp.W{i}", 2 * HID if (kind == "Vhg" and i == 1) else HID, HID)
         L.add(f"mlp.b{i}", HID)
         L.add(f"mlp.g{i}", HID)
         L.add(f"mlp.be{i}", HID)
@@ -120,7 +121,7 @@ class Net:
     def __init__(self, kind: str, cfg: N.EnvCfg, gnn_layers: int, n_out: int, device, grads: Optional[torch.Tensor] = None):
         """grads: optional caller-owned flat gradient buffer (a slice of the engine's [g_policy | g_Vl | g_Vh | scalars]
         buffer, so that the data-parallel update all-reduces ALL gradients with one collective)."""
-        assert kind in ("policy", "Vl", "Vh")
+        assert kind in ("policy", "Vl", "Vh", "Vhg")
         self.kind, self.cfg, self.gnn_layers, self.n_out, self.device = kind, cfg, gnn_layers, n_out, device
         self.layout = make_layout(kind, cfg.node_dim, gnn_layers, n_out)
         self.params = torch.zeros(self.layout.size, device=device)
@@ -213,16 +214,33 @@ class Net:
             x, Rh, n_inner = pooled, G, 1
         else:
             x, Rh, n_inner = Xa, R, n
+        if self.kind == "Vhg":   # [x_i | mean over the graph's agents, tiled] (value.py:66-68): data movement + one mean kernel
+            pooled = A.get(f"{tag}.pool", G, OUT_DIM)
+            K.mean_agents(Xa, pooled, G, n, OUT_DIM)
+            xcat = A.get(f"{tag}.xcat", R, 2 * OUT_DIM)
+            xcat[:, :OUT_DIM].copy_(Xa)
+            xcat.view(G, n, 2 * OUT_DIM)[:, :, OUT_DIM:].copy_(pooled.view(G, 1, OUT_DIM).expand(G, n, OUT_DIM))
+            x = xcat
         act["Rh"], act["n_inner"], act["mlp_in"] = Rh, n_inner, x
-        # MLP trunk (2 x Dense -> LayerNorm -> ReLU) + GRU input projection: one fused kernel (nn_fused.hip)
         gi = A.get(f"{tag}.gi", Rh, 3 * HID)
-        saves = None
-        if train:
-            saves = tuple(A.get(f"{tag}.{nm}{i}", Rh, w) for i in (1, 2) for nm, w in (("p", HID), ("y", HID), ("st", 2)))
-            for i in (1, 2):
-                act[f"p{i}"], act[f"y{i}"], act[f"st{i}"] = saves[3 * (i - 1):3 * i]
-        K.mlp_gi_fwd(x, self.p("mlp.W1"), self.p("mlp.b1"), self.p("mlp.g1"), self.p("mlp.be1"), self.p("mlp.W2"),
-                     self.p("mlp.b2"), self.p("mlp.g2"), self.p("mlp.be2"), self.p("gru.Wi"), self.p("gru.bi"), gi, saves)
+        if self.kind == "Vhg":
+            # 128-wide first Dense: the separate Dense / LayerNorm+ReLU kernels (the fused trunk kernel is 64-wide)
+            sv = {nm: A.get(f"{tag}.{nm}", Rh, w) for nm, w in (("p1", HID), ("y1", HID), ("st1", 2), ("p2", HID), ("y2", HID), ("st2", 2))}
+            K.dense_fwd(x, self.p("mlp.W1"), self.p("mlp.b1"), sv["p1"])
+            K.ln_relu_fwd(sv["p1"], self.p("mlp.g1"), self.p("mlp.be1"), sv["y1"], sv["st1"])
+            K.dense_fwd(sv["y1"], self.p("mlp.W2"), self.p("mlp.b2"), sv["p2"])
+            K.ln_relu_fwd(sv["p2"], self.p("mlp.g2"), self.p("mlp.be2"), sv["y2"], sv["st2"])
+            K.dense_fwd(sv["y2"], self.p("gru.Wi"), self.p("gru.bi"), gi)
+            act.update(sv)
+        else:
+            # MLP trunk (2 x Dense -> LayerNorm -> ReLU) + GRU input projection: one fused kernel (nn_fused.hip)
+            saves = None
+            if train:
+                saves = tuple(A.get(f"{tag}.{nm}{i}", Rh, w) for i in (1, 2) for nm, w in (("p", HID), ("y", HID), ("st", 2)))
+                for i in (1, 2):
+                    act[f"p{i}"], act[f"y{i}"], act[f"st{i}"] = saves[3 * (i - 1):3 * i]
+            K.mlp_gi_fwd(x, self.p("mlp.W1"), self.p("mlp.b1"), self.p("mlp.g1"), self.p("mlp.be1"), self.p("mlp.W2"),
+                         self.p("mlp.b2"), self.p("mlp.g2"), self.p("mlp.be2"), self.p("gru.Wi"), self.p("gru.bi"), gi, saves)
         hs = hs_out if hs_out is not None else A.get(f"{tag}.hs", Rh, HID)
         hprev = A.get(f"{tag}.hprev", Rh, HID) if train else None
         gates = A.get(f"{tag}.gates", Rh, 4 * HID) if train else None
@@ -290,13 +308,22 @@ class Net:
             K.ln_relu_bwd(act[f"p{i}"], act[f"y{i}"], act[f"st{i}"], self.p(f"mlp.g{i}"), dy, dpre, self.g(f"mlp.g{i}"),
                           self.g(f"mlp.be{i}"))
             K.dense_bwd_w(x_in[i], dpre, self.g(f"mlp.W{i}"), self.g(f"mlp.b{i}"))
-            dy = A.get(f"{tag}.dyy{i}", Rh, HID)
+            dy = A.get(f"{tag}.dyy{i}", Rh, HID if not (self.kind == "Vhg" and i == 1) else 2 * HID)
             # i == 1 for the per-agent nets: this IS the gradient of the last GNN layer's output -> ReLU backward fused here
             K.dense_fwd(dpre, self.p(f"mlp.W{i}"), None, dy, trans_w=True,
-                        relu_mask=top if (i == 1 and self.kind != "Vl") else None)
+                        relu_mask=top if (i == 1 and self.kind in ("policy", "Vh")) else None)
         if self.kind == "Vl":
             dXa = A.get(f"{tag}.dXaL", R, OUT_DIM)
             K.mean_agents(dy, dXa, G, n, OUT_DIM, backward=True, relu_mask=top)
+        elif self.kind == "Vhg":
+            # dy [R, 128] = gradient of [x_i | tiled mean]: d x_i = dy[:, :64] + (1/n) sum_j dy[g, j, 64:]  (then relu')
+            dXa = A.get(f"{tag}.dXaL", R, OUT_DIM)
+            dXa.copy_(dy[:, :OUT_DIM])
+            dglob = A.get(f"{tag}.dglob", R, OUT_DIM)
+            dglob.copy_(dy[:, OUT_DIM:])
+            dpool = A.get(f"{tag}.dpool", G, OUT_DIM)
+            K.mean_agents(dglob, dpool, G, n, OUT_DIM)                               # (1/n) sum over the graph's agents
+            K.mean_agents(dpool, dXa, G, n, OUT_DIM, backward=2, relu_mask=top)      # broadcast-add, through relu'
         else:
             dXa = dy
         # From here on dXa / dXo arrive ALREADY multiplied by relu'(layer output): the kernel that finishes each gradient

@@ -62,3 +62,28 @@ def clip_adam_step(params, grads, m, v, state, lr, max_norm, b1=0.9, b2=0.999, e
                                       C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(max_norm),
                                       C.c_float(grad_scale), N.stream_ptr())
     N.check(rc, "dgppo_clip_adam_step")
+
+
+def advantage_lagr(Ql, Vl, Qh, Vh, lagr, adv, Ah):
+    """InforMARL-Lagrangian advantage (informarl_lagr.py:219-235)"""
+    B, T, n, nh = Qh.shape
+    N.expect_shape(Ql, (B, T), "Ql"); N.expect_shape(Vl, (B, T + 1), "Vl"); N.expect_shape(Vh, (B, T + 1, n, nh), "Vh")
+    N.expect_shape(lagr, (n, nh), "lagr"); N.expect_shape(adv, (B, T, n), "adv"); N.expect_shape(Ah, (B, T, n, nh), "Ah")
+    rc = N.lib().dgppo_advantage_lagr(N.ptr(Ql), N.ptr(Vl), N.ptr(Qh), N.ptr(Vh), N.ptr(lagr), N.ptr(adv), N.ptr(Ah), B, T, n, nh,
+                                      N.stream_ptr())
+    N.check(rc, "dgppo_advantage_lagr")
+
+
+def lagr_update(lp_new, lp_old, Vh_mb, Ah_mb, lagr, sums, gamma: float, lr: float):
+    """update_lagr (informarl_lagr.py:286-309).  lp_* [Eb,T,n]; Vh_mb [Eb,T+1,n,nh] (first T steps used); Ah_mb [Eb,T,n,nh]."""
+    Eb, T, n, nh = Ah_mb.shape
+    N.expect_shape(lp_new, (Eb, T, n), "lp_new"); N.expect_shape(lp_old, (Eb, T, n), "lp_old")
+    N.expect_shape(Vh_mb, (Eb, T + 1, n, nh), "Vh"); N.expect_shape(lagr, (n, nh), "lagr"); N.expect_shape(sums, (n * nh,), "sums")
+    rc = N.lib().dgppo_lagr_update(N.ptr(lp_new), N.ptr(lp_old), N.ptr(Vh_mb), C.c_int64((T + 1) * n * nh), N.ptr(Ah_mb),
+                                   N.ptr(lagr), N.ptr(sums), Eb, T, n, nh, C.c_float(1.0 - gamma), C.c_float(lr), N.stream_ptr())
+    N.check(rc, "dgppo_lagr_update")
+
+
+def relu_fwd(x, out):
+    rc = N.lib().dgppo_relu_fwd(N.ptr(x), N.ptr(out), C.c_int64(x.numel()), N.stream_ptr())
+    N.check(rc, "dgppo_relu_fwd")

@@ -238,6 +238,7 @@ def value_loss(v, target, dv, stats):
 
 
 def mean_agents(x, y, G, n, D, backward=False, relu_mask=None):
+    """backward: False/0 mean, True/1 gradient of the mean, 2 broadcast-add (see the header)"""
     rc = N.lib().dgppo_mean_agents(_p(x), _p(y), G, n, D, int(backward), _p(relu_mask), N.stream_ptr())
     N.check(rc, "dgppo_mean_agents")
 

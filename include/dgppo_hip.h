@@ -228,8 +228,10 @@ int32_t dgppo_policy_head(const float* ms, const float* eps, const float* action
 
 /* optax.l2_loss(v, target).mean() (informarl.py:374, dgppo.py:310): dv = (v-target)/count, stats[0] += sum 1/2 d^2 */
 int32_t dgppo_value_loss(const float* v, const float* target, float* dv, float* stats, int32_t count, void* stream);
-/* mean over the n agents of each graph (value.py:33): x [G,n,D] -> y [G,D]; backward: x = dy [G,D] -> y = dx [G,n,D],
- * optionally through the ReLU that produced the pooled rows (relu_mask [G,n,D] = that ReLU's output, or NULL)            */
+/* mean over the n agents of each graph (value.py:33): x [G,n,D] -> y [G,D]; backward = 1: x = dy [G,D] -> y = dx [G,n,D]
+ * (= x / n); backward = 2: y[g,i,:] += x[g,:] (broadcast-add of a per-graph row, the tiled global feature of
+ * DecRStateFn(use_global_info=True), value.py:66-68); both optionally through the ReLU that produced the pooled rows
+ * (relu_mask [G,n,D] = that ReLU's output, or NULL)                                                                      */
 int32_t dgppo_mean_agents(const float* x, float* y, int32_t G, int32_t n, int32_t D, int32_t backward,
                           const float* relu_mask, void* stream);
 /* dy *= (y > 0), in place                                                                                             */
@@ -248,6 +250,19 @@ int32_t dgppo_gae(const float* costs, const float* rewards, const float* Vh, con
 int32_t dgppo_advantage(const float* Ql, const float* Vl, const float* Vh, float dt, float alpha, float cbf_eps,
                         float cbf_weight, float* adv, float* stats, int32_t B, int32_t T, int32_t n, int32_t nh,
                         void* stream);
+/* InforMARL-Lagrangian advantage (dgppo/algo/informarl_lagr.py:219-235): Al = (Ql - Vl) standardised per env over T, Ah =
+ * (Qh - Vh[:, :T]) standardised per (env, agent, component) over T (population std, + 1e-8), adv = -Al - mean_h(Ah *
+ * lagr[a,h]).  Ql [B,T], Vl [B,T+1], Qh [B,T,n,nh], Vh [B,T+1,n,nh], lagr [n,nh] -> adv [B,T,n], Ah [B,T,n,nh].          */
+int32_t dgppo_advantage_lagr(const float* Ql, const float* Vl, const float* Qh, const float* Vh, const float* lagr,
+                             float* adv, float* Ah, int32_t B, int32_t T, int32_t n, int32_t nh, void* stream);
+/* update_lagr (informarl_lagr.py:286-309) on one minibatch of n_env envs: delta[a,h] = -mean_{env,t}(Vh (1 - gamma) +
+ * exp(lp_new - lp_old) Ah), lagr = relu(lagr - delta * lr).  lp_* [n_env,T,n], Ah [n_env,T,n,nh] (gathered), Vh: base of
+ * the gathered value rows with vh_env_stride floats between envs (first T steps used), sums [n*nh]: zeroed scratch.    */
+int32_t dgppo_lagr_update(const float* lp_new, const float* lp_old, const float* Vh, int64_t vh_env_stride,
+                          const float* Ah, float* lagr, float* sums, int32_t n_env, int32_t T, int32_t n, int32_t nh,
+                          float one_minus_gamma, float lr, void* stream);
+/* out = max(x, 0): jnp.clip(rollout.costs, a_min=0) of informarl_lagr.py:213                                             */
+int32_t dgppo_relu_fwd(const float* x, float* out, int64_t count, void* stream);
 /* InforMARL's stage cost l = -reward + w * sum_{agents, components} max(cost, 0) (dgppo/algo/informarl.py:329), as the
  * equivalent reward out = reward - w * sum(...) for dgppo_gae.  reward/out [rows], cost [rows, n, nh].              */
 int32_t dgppo_shaped_reward(const float* reward, const float* cost, float cost_weight, float* out, int64_t rows,

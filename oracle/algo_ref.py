@@ -111,3 +111,23 @@ def informarl_targets(costs, rewards, Vl, gamma, lam, cost_weight):
     Al = Ql - Vl[:, :-1]
     Al = (Al - Al.mean(axis=1, keepdims=True)) / (Al.std(axis=1, keepdims=True) + 1e-8)
     return Ql.astype(f32), (-np.repeat(Al[:, :, None], n, axis=-1)).astype(f32)
+
+
+def advantage_lagr(Ql, Vl, Qh, Vh, lagr):
+    """dgppo/algo/informarl_lagr.py:219-235.  Ql [B,T], Vl [B,T+1], Qh [B,T,n,nh], Vh [B,T+1,n,nh], lagr [n,nh]
+    -> A [B,T,n], Ah (standardised constraint advantage) [B,T,n,nh]."""
+    n = Qh.shape[2]
+    Al = Ql - Vl[:, :-1]
+    Al = (Al - Al.mean(axis=1, keepdims=True)) / (Al.std(axis=1, keepdims=True) + 1e-8)
+    Ala = -np.repeat(Al[:, :, None], n, axis=-1)
+    Ah = Qh - Vh[:, :-1]
+    Ah = (Ah - Ah.mean(axis=1, keepdims=True)) / (Ah.std(axis=1, keepdims=True) + 1e-8)
+    A = Ala - (Ah * lagr[None, None]).mean(axis=-1)
+    return A.astype(f32), Ah.astype(f32)
+
+
+def lagr_update(lagr, lp_new, lp_old, Vh, Ah, gamma, lr):
+    """update_lagr (informarl_lagr.py:300-308).  lp_* [b,T,n], Vh [b,T,n,nh] (the first T values), Ah [b,T,n,nh]."""
+    ratio = np.exp(lp_new - lp_old)
+    delta = -(Vh * (1.0 - gamma) + ratio[..., None] * Ah).mean(axis=(0, 1))
+    return np.maximum(lagr - delta * lr, 0.0).astype(f32)

@@ -156,3 +156,73 @@ def minibatch_losses(trees, ocfg, ro, det, tg, idx, hp, eps_hat):
     out.update({"policy/loss": float(loss_pol.detach()), "policy/clip_frac": float((l2 > l1).float().mean()),
                 "policy/entropy": float(ent.mean().detach()), "policy/total_variation_dist": float(0.5 * (rho - 1).abs().mean().detach())})
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# InforMARL-Lagrangian (dgppo/algo/informarl_lagr.py:125-309)
+# ----------------------------------------------------------------------------------------------------------------------
+def values_Vh_lagr(trees, ocfg, ro):
+    """scan_Vh over the T graphs with the net's OWN zero-initialised carry + the final value on next_graph[-1]
+    (informarl_lagr.py:151-161,194-207): Vh [B,T+1,n,nh].  The net is DecRStateFn(use_global_info=True)."""
+    n = ocfg.n_agents
+    g = graphs_of(ocfg, ro["agent"], ro["goal"], ro["obst"], ro["hits"])
+    B, T1 = ro["agent"].shape[:2]
+    with torch.no_grad():
+        h = torch.zeros(B, n, 64)
+        vs = []
+        for t in range(T1):
+            v, h = T.value_Vh(trees["Vh"], _sel(g, t=t), h, n, global_info=True)
+            vs.append(v)
+    return torch.stack(vs, 1).numpy()
+
+
+def targets_lagr(trees, ocfg, ro, hp, lagr):
+    Vl = values_Vl(trees, ocfg, ro)
+    Vh = values_Vh_lagr(trees, ocfg, ro)
+    Qh, Ql = A.gae_batch(np.maximum(ro["costs"], 0.0), ro["rewards"], Vh, Vl, hp["gamma"], hp["gae_lambda"])
+    adv, Ah = A.advantage_lagr(Ql, Vl, Qh, Vh, lagr)
+    return dict(Vl=Vl, Vh=Vh, Ql=Ql, Qh=Qh, adv=adv, Ah=Ah)
+
+
+def minibatch_losses_lagr(trees, ocfg, ro, tg, idx, hp, eps_hat):
+    """Vl / policy losses as InforMARL, plus update_Vh of the Lagrangian baseline: chunks of rnn_step with zero initial
+    carry against Qh (informarl_lagr.py:252-284).  trees must have requires_grad leaves."""
+    out = minibatch_losses({"policy": trees["policy"], "Vl": trees["Vl"]}, ocfg, ro, None, tg, idx, hp, eps_hat)
+    n, rs = ocfg.n_agents, hp["rnn_step"]
+    B, T1 = ro["agent"].shape[:2]
+    Tn = T1 - 1
+    C = Tn // rs
+    sub = lambda d, k: None if d[k] is None else d[k][idx]
+    g = graphs_of(ocfg, ro["agent"][idx][:, :Tn], sub(ro, "goal"), sub(ro, "obst"),
+                  None if ro["hits"] is None else ro["hits"][idx][:, :Tn])
+    Eb = len(idx)
+    gc = {k: v.reshape((Eb * C, rs) + v.shape[2:]) for k, v in g.items()}
+    h = torch.zeros(Eb * C, n, 64)
+    vs = []
+    for tau in range(rs):
+        v, h = T.value_Vh(trees["Vh"], _sel(gc, t=tau), h, n, global_info=True)
+        vs.append(v)
+    vh = torch.stack(vs, 1).reshape(Eb, Tn, n, -1)
+    loss_Vh = (0.5 * (vh - torch.from_numpy(tg["Qh"][idx])) ** 2).mean()
+    loss_Vh.backward()
+    out["Vh/loss"] = float(loss_Vh.detach())
+    return out
+
+
+def log_pi_full_episode(trees, ocfg, ro, idx, eps_hat):
+    """log pi of the stored actions re-evaluated over the WHOLE episode from a zero carry (update_lagr,
+    informarl_lagr.py:287-299): [len(idx), T, n]."""
+    n = ocfg.n_agents
+    B, T1 = ro["agent"].shape[:2]
+    Tn = T1 - 1
+    sub = lambda d, k: None if d[k] is None else d[k][idx]
+    g = graphs_of(ocfg, ro["agent"][idx][:, :Tn], sub(ro, "goal"), sub(ro, "obst"),
+                  None if ro["hits"] is None else ro["hits"][idx][:, :Tn])
+    acts = torch.from_numpy(ro["actions"][idx])
+    h = torch.zeros(len(idx), n, 64)
+    lps = []
+    with torch.no_grad():
+        for t in range(Tn):
+            lp, _, h = T.policy_eval(trees["policy"], _sel(g, t=t), acts[:, t], h, n, eps_hat)
+            lps.append(lp)
+    return torch.stack(lps, 1).numpy()

@@ -106,12 +106,13 @@ def init_policy(seed: int, node_dim: int, action_dim: int = 2, gnn_layers: int =
     }}
 
 
-def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int):
-    """Vl.pkl / Vh.pkl trees (dgppo/algo/module/value.py:15-79)."""
+def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, global_info: bool = False):
+    """Vl.pkl / Vh.pkl trees (dgppo/algo/module/value.py:15-79).  global_info: DecRStateFn(use_global_info=True), whose
+    head sees [x_i | mean_j x_j] (value.py:66-68), i.e. a 128-wide first Dense."""
     gen = torch.Generator().manual_seed(seed)
     return {"params": {
         "GraphTransformerGNN_0": init_gnn(gen, node_dim, gnn_layers),
-        "ValueGNNHead": init_mlp(gen, 64),
+        "ValueGNNHead": init_mlp(gen, 128 if global_info else 64),
         "RNN_0": {"GRUCell_1": init_gru(gen)},
         "Dense_0": _dense(gen, 64, n_out),
     }}
@@ -301,10 +302,13 @@ def value_Vl(vp, graph, h, n_agents):
     return dense(p["Dense_0"], new_h)[:, 0, 0], new_h
 
 
-def value_Vh(vp, graph, h, n_agents):
-    """DecRStateFn(use_global_info=False): GNN -> agents -> MLP -> GRU -> Dense n_cost.  h [G,n,64] -> [G,n,n_cost]."""
+def value_Vh(vp, graph, h, n_agents, global_info: bool = False):
+    """DecRStateFn: GNN -> agents [-> concat the mean over agents, tiled (use_global_info, value.py:66-68)] -> MLP -> GRU ->
+    Dense n_cost.  h [G,n,64] -> [G,n,n_cost]."""
     p = vp["params"]
     x = gnn(p["GraphTransformerGNN_0"], graph, n_agents)
+    if global_info:
+        x = torch.cat([x, x.mean(dim=1, keepdim=True).expand(-1, n_agents, -1)], dim=-1)
     x = mlp(p["ValueGNNHead"], x)
     new_h = gru_cell(p["RNN_0"]["GRUCell_1"], h, x)
     return dense(p["Dense_0"], new_h), new_h

@@ -73,3 +73,30 @@ def test_clip_adam_matches_optax_semantics(cuda):
         np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=0, atol=2e-6)
     np.testing.assert_allclose(m.cpu().numpy(), mr, rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(v.cpu().numpy(), vr, rtol=1e-4, atol=1e-10)
+
+
+def test_lagrangian_kernels(cuda):
+    """dgppo_advantage_lagr / dgppo_lagr_update / dgppo_relu_fwd against oracle/algo_ref.py (informarl_lagr.py:213-235,286-309)"""
+    from dgppo_amd import ops_algo as O
+    r = np.random.default_rng(3)
+    B, T, n, nh = 7, 32, 8, 2
+    Ql = r.normal(size=(B, T)).astype(np.float32); Vl = r.normal(size=(B, T + 1)).astype(np.float32)
+    Qh = r.normal(size=(B, T, n, nh)).astype(np.float32); Vh = r.normal(size=(B, T + 1, n, nh)).astype(np.float32)
+    lagr = r.uniform(0, 1, size=(n, nh)).astype(np.float32)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(cuda)
+    adv = torch.empty(B, T, n, device=cuda); Ah = torch.empty(B, T, n, nh, device=cuda)
+    O.advantage_lagr(d(Ql), d(Vl), d(Qh), d(Vh), d(lagr), adv, Ah)
+    wA, wAh = A.advantage_lagr(Ql, Vl, Qh, Vh, lagr)
+    np.testing.assert_allclose(Ah.cpu().numpy(), wAh, atol=1e-5)
+    np.testing.assert_allclose(adv.cpu().numpy(), wA, atol=1e-5)
+    lp_new = (r.normal(size=(B, T, n)) * 0.3).astype(np.float32); lp_old = (r.normal(size=(B, T, n)) * 0.3).astype(np.float32)
+    lg = d(lagr.copy()); sums = torch.zeros(n * nh, device=cuda)
+    for lr in (0.5, 50.0):                                       # the second step drives some multipliers to the clip at 0
+        O.lagr_update(d(lp_new), d(lp_old), d(Vh), d(wAh), lg, sums, 0.99, lr)
+        lagr = A.lagr_update(lagr, lp_new, lp_old, Vh[:, :T], wAh, 0.99, lr)
+        np.testing.assert_allclose(lg.cpu().numpy(), lagr, atol=1e-5 * max(1.0, float(np.abs(lagr).max())))
+        assert float(sums.abs().max()) == 0.0
+    assert (lagr == 0).any() and (lagr > 0).any()
+    x = d(r.normal(size=(1000,)).astype(np.float32)); y = torch.empty_like(x)
+    O.relu_fwd(x, y)
+    assert torch.equal(y, torch.clamp_min(x, 0.0))

@@ -450,3 +450,63 @@ def test_update_hip_graph_replay_equals_eager(cuda, algo):
         for k in infos[0]:
             assert abs(infos[0][k] - infos[1][k]) <= 1e-5 * max(1.0, abs(infos[0][k])), (it, k)
     assert eng_g._upd_graph.get("graph") is not None, "the minibatch step was never captured"
+
+
+def test_informarl_lagr_targets_gradients_and_multipliers(cuda):
+    """Engine(algo="informarl_lagr") (dgppo/algo/informarl_lagr.py:125-309): Vl and the global-info Vh
+    scanned with their own carries, GAE on the clipped costs, the Lagrangian advantage, first-minibatch gradients of
+    Vl / Vh / policy, and the multiplier update after the policy step — all against the oracle."""
+    from dgppo_amd import engine as EN, init
+    from oracle import algo_ref as A
+    kind, n, n_obs, B, T_, rs = "LidarSpread", 3, 2, 4, 8, 4
+    bs = B * T_                                                       # ONE minibatch: the multiplier is checked after it
+    cfg, ocfg, hp0, eng0, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs)
+    hp = EN.Hyper(batch_size=bs, rnn_step=rs, train_steps=100, lagr_init=0.4, lr_lagr=0.05)
+    eng = EN.Engine(cfg, hp, cuda, T=T_, algo="informarl_lagr", multi_stream=True)
+    gen = torch.Generator().manual_seed(21)
+    trees["Vh"] = T.tree_map(lambda t: t + 0.05 * torch.randn(t.shape, generator=gen), T.init_value(5, cfg.node_dim, 2, 1, global_info=True))
+    for k, net in eng.nets.items():
+        net.load_tree(trees[k])
+    eng.set_entropy_noise(77)
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    ro = eng.rollout(seeds, True, noise_seed=3).finalize()
+    r = _np_rollout(ro)
+    hpd = dict(gamma=hp.gamma, gae_lambda=hp.gae_lambda, rnn_step=rs, clip_eps=hp.clip_eps, coef_ent=hp.coef_ent)
+    lagr0 = eng.lagr.cpu().numpy().copy()
+    assert np.all(lagr0 == np.float32(0.4))
+    tg = eng.targets_lagr(ro, 0)
+    leaf = {k: T.tree_map(lambda t: t.clone().requires_grad_(), v) for k, v in trees.items()}
+    wt = R.targets_lagr(leaf, ocfg, r, hpd, lagr0)
+    for k in ("Vl", "Vh", "Ql", "Qh"):
+        _close(tg[k], wt[k], k)
+    # standardised advantages: kernel on the device's own inputs to 1e-5, end to end within the propagated bound
+    g = {k: tg[k].cpu().numpy() for k in ("Vl", "Vh", "Ql", "Qh", "adv", "Ah")}
+    same_A, same_Ah = A.advantage_lagr(g["Ql"], g["Vl"], g["Qh"], g["Vh"], lagr0)
+    _close(g["adv"], same_A, "lagr advantage kernel on identical inputs")
+    _close(g["Ah"], same_Ah, "Ah kernel on identical inputs")
+    stdh = (wt["Qh"] - wt["Vh"][:, :-1]).std(axis=1, keepdims=True) + 1e-8
+    bound_h = 4.0 * (np.abs(g["Qh"] - wt["Qh"]).max() + np.abs(g["Vh"] - wt["Vh"]).max()) / stdh + 1e-5
+    assert (np.abs(g["Ah"] - wt["Ah"]) <= bound_h).all()
+    perm = np.arange(B)
+    grads = {}
+
+    def hook(name, net, mb):
+        if mb == 0:
+            grads[name] = net.to_tree(net.grads)
+    eng.grad_hook = hook
+    tg_np = {k: v.cpu().numpy() for k, v in tg.items()}
+    R.minibatch_losses_lagr(leaf, ocfg, r, tg_np, perm, hpd, eng.eps_hat.cpu())
+    info = eng.update(ro, None, 0, perm)
+    torch.cuda.synchronize()
+    _check_first_minibatch_grads(leaf, grads, ("Vl", "Vh", "policy"))
+    for k in ("Vh/loss", "Vh/grad_norm", "Vh/has_nan", "Vh/max_target", "Vh/min_target", "policy/lagr_mean", "Vl/loss", "policy/loss"):
+        assert k in info and np.isfinite(info[k]), k
+    assert "eval/safe_data" not in info
+    # multiplier update with the UPDATED policy (informarl_lagr.py:286-309): oracle evaluation of the device's new parameters
+    new_pol = T.tree_map(lambda a: torch.from_numpy(np.ascontiguousarray(a)), eng.policy.to_tree())
+    lp_new = R.log_pi_full_episode({"policy": new_pol}, ocfg, r, perm, eng.eps_hat.cpu())
+    want = A.lagr_update(lagr0, lp_new, r["log_pis"], tg_np["Vh"][:, :T_], tg_np["Ah"], hp.gamma, hp.lr_lagr)
+    got = eng.lagr.cpu().numpy()
+    assert not np.array_equal(got, lagr0)
+    np.testing.assert_allclose(got, want, atol=2e-6)
+    assert abs(info["policy/lagr_mean"] - float(want.mean())) < 1e-5

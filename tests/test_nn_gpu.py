@@ -638,3 +638,41 @@ def test_mean_agents_backward_with_relu_mask(cuda):
     torch.cuda.synchronize()
     assert torch.equal(b, torch.where(y > 0, a, torch.zeros_like(a)))
     assert torch.equal(a.view(G, n, D)[:, 3], dy / n)
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [(E.LIDAR_SPREAD, 8, 3), (E.MPE_SPREAD, 3, 3)])
+def test_Vh_global_info_forward_backward(cuda, kind, n, n_obs):
+    """the Lagrangian baseline's constraint-value net: DecRStateFn(use_global_info=True) (value.py:61-79 — the head sees
+    [x_i | mean_j x_j], 128-wide first Dense) scanned over time with its OWN carry (informarl_lagr.py:151-161)."""
+    from dgppo_amd import nets, ops_nn as K_
+    n_env, T_ = 3, 4
+    cfg, ocfg, ag, goal, obst, hi, gr = _scene(kind, n, n_obs, n_env, T_, seed=6)
+    gen = torch.Generator().manual_seed(8)
+    tree = T.tree_map(lambda t: t + 0.05 * torch.randn(t.shape, generator=gen), T.init_value(3, cfg.node_dim, 2, 1, global_info=True))
+    assert tuple(tree["params"]["ValueGNNHead"]["Dense_0"]["kernel"].shape) == (128, 64)
+    net = nets.Net("Vhg", cfg, 1, 2, cuda)
+    net.load_tree(tree)
+    back = net.to_tree()
+    np.testing.assert_array_equal(back["params"]["ValueGNNHead"]["Dense_0"]["kernel"], tree["params"]["ValueGNNHead"]["Dense_0"]["kernel"].numpy())
+    feats = _feats(cfg, ag, goal, obst, hi, cuda)
+    G = n_env * T_
+    act = net.forward(feats, n_seq=n_env * n, T=T_, h0=None)       # sequences = (env, agent), zero initial carry
+    lt = _leafify(tree)
+    g_t = T.graph_to_torch(gr)
+    sel = lambda t: {k: v.view((n_env, T_) + v.shape[1:])[:, t] for k, v in g_t.items()}
+    h = torch.zeros(n_env, n, 64)
+    vs = []
+    for t in range(T_):
+        v, h = T.value_Vh(lt, sel(t), h, n, global_info=True)
+        vs.append(v)
+    v_w = torch.stack(vs, 1)                                        # [n_env, T, n, 2]
+    _close(act["v"].view(n_env, T_, n, 2), v_w, 1e-5, "Vh(global)")
+    target = torch.randn(n_env, T_, n, 2, generator=gen)
+    (0.5 * (v_w - target) ** 2).mean().backward()
+    dv = torch.empty(G * n, 2, device=cuda)
+    stats = torch.zeros(8, device=cuda)
+    K_.value_loss(act["v"], target.reshape(-1, 2).to(cuda), dv, stats)
+    net.zero_grads()
+    net.backward(act, dv)
+    torch.cuda.synchronize()
+    _grad_tree_close(net, lt, 3e-5)

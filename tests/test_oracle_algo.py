@@ -119,3 +119,28 @@ def test_informarl_targets_known_answers():
     # schedule
     assert A.cost_weight_schedule(0.5, 10, 100, enabled=False) == 0.5
     assert [A.cost_weight_schedule(0.5, s, 100, enabled=True) for s in (0, 49, 50, 74, 75, 99)] == [0.5, 0.5, 2.5, 2.5, 12.5, 12.5]
+
+
+def test_lagrangian_advantage_and_multiplier_known_answers():
+    """informarl_lagr.py:219-235,300-308 with hand-checkable numbers."""
+    from oracle import algo_ref as A
+    # one env, T = 2, one agent, one component: Al = Ql - Vl = [1, 3] -> standardised [-1, 1] -> negated [1, -1];
+    # Ah = Qh - Vh = [2, 0] -> [1, -1]; lagr = 0.5  ->  A = [1, -1] - 0.5 * [1, -1] = [0.5, -0.5]
+    Ql = np.array([[2.0, 5.0]], np.float32); Vl = np.array([[1.0, 2.0, 9.0]], np.float32)
+    Qh = np.array([[[[3.0]], [[1.0]]]], np.float32); Vh = np.array([[[[1.0]], [[1.0]], [[7.0]]]], np.float32)
+    A_, Ah = A.advantage_lagr(Ql, Vl, Qh, Vh, np.array([[0.5]], np.float32))
+    np.testing.assert_allclose(Ah[0, :, 0, 0], [1.0, -1.0], atol=1e-6)
+    np.testing.assert_allclose(A_[0, :, 0], [0.5, -0.5], atol=1e-6)
+    # two components average (mean over h): lagr = [1, 3], Ah identical in both -> A = -Al - (1 + 3) / 2 * Ah
+    Qh2 = np.repeat(Qh, 2, axis=-1); Vh2 = np.repeat(Vh, 2, axis=-1)
+    A2, _ = A.advantage_lagr(Ql, Vl, Qh2, Vh2, np.array([[1.0, 3.0]], np.float32))
+    np.testing.assert_allclose(A2[0, :, 0], [1.0 - 2.0, -1.0 + 2.0], atol=1e-6)
+    # multiplier: rho = 1 (lp_new == lp_old): delta = -mean(Vh (1 - gamma) + Ah); lagr' = relu(lagr - delta lr)
+    lp = np.zeros((1, 2, 1), np.float32)
+    Vh_T = np.array([[[[2.0]], [[4.0]]]], np.float32); Ah_T = np.array([[[[1.0]], [[-3.0]]]], np.float32)
+    got = A.lagr_update(np.array([[0.5]], np.float32), lp, lp, Vh_T, Ah_T, gamma=0.9, lr=0.1)
+    want = 0.5 + 0.1 * ((2.0 * 0.1 + 1.0) + (4.0 * 0.1 - 3.0)) / 2
+    np.testing.assert_allclose(got, [[want]], atol=1e-6)
+    # clipped at zero, and the ratio scales the advantage term
+    got = A.lagr_update(np.array([[0.01]], np.float32), lp + np.log(2.0).astype(np.float32), lp, Vh_T * 0, -np.abs(Ah_T), 0.9, 1.0)
+    assert got[0, 0] == 0.0
