@@ -58,6 +58,18 @@ def _unflatten_tree(v, B, T):
     return v
 
 
+def _check_rnn_options(use_rnn: bool, use_lstm: bool, rnn_layers: int):
+    """GRU cells (any number of stacked layers, dgppo/nn/rnn.py:17-29) and --no-rnn are built; the LSTM cell is not"""
+    if use_rnn and use_lstm:
+        raise NotImplementedError("--use-lstm: this build implements the GRU cell (the reference default) and --no-rnn; "
+                                  "flax LSTMCell (dgppo/nn/rnn.py:22-24) is not built")
+    assert rnn_layers >= 1
+
+
+def _n_cells(use_rnn: bool, rnn_layers: int) -> int:
+    return rnn_layers if use_rnn else 0
+
+
 class DGPPO(Algorithm):
     def __init__(self, env, node_dim: int, edge_dim: int, state_dim: int, action_dim: int, n_agents: int,
                  actor_gnn_layers: int = 2, Vl_gnn_layers: int = 2, Vh_gnn_layers: int = 1, gamma: float = 0.99,
@@ -67,9 +79,8 @@ class DGPPO(Algorithm):
                  use_lstm: bool = False, alpha: float = 10.0, cbf_eps: float = 1e-2, cbf_weight: float = 1.0,
                  train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, world: int = 1, **kwargs):
         super().__init__(env, node_dim, edge_dim, action_dim, n_agents)
-        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
-            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1 "
-                                      "(LSTM / no-rnn are next-tier, SURVEY §2 row 9)")
+        _check_rnn_options(use_rnn, use_lstm, rnn_layers)
+        assert epoch_ppo >= 1
         assert node_dim == env.node_dim and action_dim == 2
         self.state_dim = state_dim
         self.seed = seed
@@ -78,19 +89,36 @@ class DGPPO(Algorithm):
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
                            rnn_step=rnn_step, alpha=alpha, cbf_eps=cbf_eps, cbf_weight=cbf_weight, cbf_schedule=cbf_schedule,
                            train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers, Vl_gnn_layers=Vl_gnn_layers,
-                           Vh_gnn_layers=Vh_gnn_layers)
+                           Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers)
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
                                 use_graphs=True, multi_stream=True)
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
-        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3))
+        nc = _n_cells(use_rnn, rnn_layers)
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
+        # the constraint-value net is built with ValueNet's default of one cell (dgppo.py:83-95)
+        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3, rnn_layers=min(nc, 1)))
         # np.random.randint(0, 102400) at trace time in the reference (distribution.py:40)
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
         # (n_rnn_layers, n_agents, n_carries, rnn_state_dim), zeros (informarl.py:115-124)
         self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
         self._single = nets.Arena(self.device)
+
+    # ---- carry layout: the reference's (n_layers, n_agents, n_carries = 1, 64) <-> the engine's packed rows [n, L * 64] ----
+    def _pack_carry(self, rnn_state) -> torch.Tensor:
+        n, HC = self.n_agents, self.engine.HC
+        x = torch.as_tensor(rnn_state, dtype=torch.float32, device=self.device).reshape(-1, n, nets.HID)
+        x = x[:max(HC // nets.HID, 1)]
+        return x.permute(1, 0, 2).reshape(n, HC).contiguous()
+
+    def _unpack_carry(self, rows: torch.Tensor) -> torch.Tensor:
+        """[..., n, L * 64] -> [..., L, n, 1, 64]"""
+        n, L = self.n_agents, max(self.engine.HC // nets.HID, 1)
+        lead = rows.shape[:-2]
+        x = rows.reshape(lead + (n, L, nets.HID))
+        perm = tuple(range(len(lead))) + (len(lead) + 1, len(lead), len(lead) + 2)
+        return x.permute(perm).unsqueeze(-2)
 
     # ---- reference properties ----
     @property
@@ -121,10 +149,10 @@ class DGPPO(Algorithm):
         st = env._state_of(graph)
         n = cfg.n_agents
         feats = self.engine._feats_at("one", st.agent, st.hits, st.goal, st.obst, 1)
-        h0 = torch.as_tensor(rnn_state, dtype=torch.float32, device=self.device).reshape(n, nets.HID).contiguous()
-        hs = torch.empty(n, nets.HID, device=self.device)
+        h0 = self._pack_carry(rnn_state)
+        hs = torch.empty(n, self.engine.HC, device=self.device)
         act = self.engine.policy.forward(feats, n_seq=n, T=1, h0=h0, tag="one", hs_out=hs, train=False)
-        return act["ms"], hs.view(1, n, 1, nets.HID)
+        return act["ms"], self._unpack_carry(hs)
 
     def act(self, graph: GraphsTuple, rnn_state, params=None):
         self._maybe_load(params)
@@ -153,7 +181,7 @@ class DGPPO(Algorithm):
     def _wrap(self, ro: EN.RolloutData, env=None) -> Rollout:
         ro.finalize()
         env = self._env if env is None else env
-        r = Rollout(_LazyGraphs(env, ro, 0), ro.actions, ro.rnn_states.unsqueeze(2).unsqueeze(4), ro.rewards, ro.costs,
+        r = Rollout(_LazyGraphs(env, ro, 0), ro.actions, self._unpack_carry(ro.rnn_states), ro.rewards, ro.costs,
                     torch.zeros(ro.B, ro.T, dtype=torch.bool, device=self.device), ro.log_pis, _LazyGraphs(env, ro, 1))
         self._last_rollouts = getattr(self, "_last_rollouts", {})
         self._last_rollouts[id(r.actions)] = ro
@@ -202,9 +230,12 @@ class DGPPO(Algorithm):
             det = pend[1]
         else:
             det = self.engine.rollout(self._seeds(self._rng.integers(1, 2 ** 62, size=ro.B)), False)
-        perm = np.arange(ro.B)
-        np.random.shuffle(perm)                              # host np.random like the reference (dgppo.py:155-156)
-        return self.engine.update(ro, det, int(step), perm)
+        info = {}
+        for _ in range(self.epoch_ppo):                      # dgppo.py:154-172: every epoch reshuffles and recomputes the targets
+            perm = np.arange(ro.B)                           # with the current parameters; the det rollout is shared (:140-141)
+            np.random.shuffle(perm)                          # host np.random like the reference (dgppo.py:155-156)
+            info = self.engine.update(ro, det, int(step), perm)
+        return info
 
     # ---- checkpoints: {dir}/{step}/{actor,Vl,Vh}.pkl with flax-named params (informarl_lagr.py:311-327) ----
     def save(self, save_dir: str, step: int):

@@ -14,7 +14,7 @@ from .. import init as INIT
 from .. import nets
 from ..utils import checkpoint as CK
 from .base import Algorithm
-from .dgppo import DGPPO
+from .dgppo import DGPPO, _check_rnn_options, _n_cells
 
 
 class InforMARL(DGPPO):
@@ -25,20 +25,22 @@ class InforMARL(DGPPO):
                  seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16, use_lstm: bool = False,
                  cost_schedule: bool = False, train_steps: int = 1e5, allreduce=None, world: int = 1, **kwargs):
         Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
-        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
-            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1")
+        _check_rnn_options(use_rnn, use_lstm, rnn_layers)
+        assert epoch_ppo >= 1
         assert node_dim == env.node_dim and action_dim == 2
         self.state_dim, self.seed = state_dim, seed
         self.epoch_ppo, self.use_rnn, self.rnn_layers, self.use_lstm = epoch_ppo, use_rnn, rnn_layers, use_lstm
         self.hp = EN.Hyper(gamma=gamma, gae_lambda=gae_lambda, clip_eps=clip_eps, coef_ent=coef_ent,
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, batch_size=batch_size,
                            rnn_step=rnn_step, train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers,
-                           Vl_gnn_layers=Vl_gnn_layers, cost_weight=cost_weight, cost_schedule=cost_schedule)
+                           Vl_gnn_layers=Vl_gnn_layers, cost_weight=cost_weight, cost_schedule=cost_schedule,
+                           use_rnn=use_rnn, rnn_layers=rnn_layers)
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
                                 use_graphs=True, multi_stream=True, algo="informarl")
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
+        nc = _n_cells(use_rnn, rnn_layers)
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
         self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
@@ -69,9 +71,12 @@ class InforMARL(DGPPO):
         if ro is None:
             raise ValueError("update() needs a Rollout produced by this algo's collect()")
         self._last_rollouts.clear()
-        perm = np.arange(ro.B)
-        np.random.shuffle(perm)                              # host np.random like the reference (informarl.py:270-271)
-        return self.engine.update(ro, None, int(step), perm)
+        info = {}
+        for _ in range(self.epoch_ppo):                      # informarl.py:267-278
+            perm = np.arange(ro.B)
+            np.random.shuffle(perm)                          # host np.random like the reference (informarl.py:270-271)
+            info = self.engine.update(ro, None, int(step), perm)
+        return info
 
     # checkpoints: {dir}/{step}/{actor,Vl}.pkl (informarl.py:459-470)
     def save(self, save_dir: str, step: int):
@@ -101,8 +106,8 @@ class HCBFCRPO(InforMARL):
                  use_lstm: bool = False, alpha: float = 10.0, cbf_eps: float = 1e-2, cbf_weight: float = 1.0,
                  train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, world: int = 1, **kwargs):
         Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
-        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
-            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1")
+        _check_rnn_options(use_rnn, use_lstm, rnn_layers)
+        assert epoch_ppo >= 1
         assert node_dim == env.node_dim and action_dim == 2
         self.state_dim, self.seed = state_dim, seed
         self.epoch_ppo, self.use_rnn, self.rnn_layers, self.use_lstm = epoch_ppo, use_rnn, rnn_layers, use_lstm
@@ -110,12 +115,13 @@ class HCBFCRPO(InforMARL):
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
                            rnn_step=rnn_step, alpha=alpha, cbf_eps=cbf_eps, cbf_weight=cbf_weight, cbf_schedule=cbf_schedule,
                            train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers, Vl_gnn_layers=Vl_gnn_layers,
-                           Vh_gnn_layers=Vh_gnn_layers)
+                           Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers)
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
                                 use_graphs=True, multi_stream=True, algo="hcbfcrpo")
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
+        nc = _n_cells(use_rnn, rnn_layers)
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
         self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
@@ -140,8 +146,8 @@ class InforMARLLagr(InforMARL):
                  use_lstm: bool = False, lagr_init: float = 0.78, lr_lagr: float = 1e-7, train_steps: int = 1e5,
                  allreduce=None, world: int = 1, **kwargs):
         Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
-        if not use_rnn or use_lstm or rnn_layers != 1 or epoch_ppo != 1:
-            raise NotImplementedError("this build covers the reference defaults: GRU, 1 rnn layer, epoch_ppo = 1")
+        _check_rnn_options(use_rnn, use_lstm, rnn_layers)
+        assert epoch_ppo >= 1
         if allreduce is not None:
             raise NotImplementedError("informarl_lagr runs on one device in this build (the multiplier update is not sharded)")
         assert node_dim == env.node_dim and action_dim == 2
@@ -150,13 +156,15 @@ class InforMARLLagr(InforMARL):
         self.hp = EN.Hyper(gamma=gamma, gae_lambda=gae_lambda, clip_eps=clip_eps, coef_ent=coef_ent,
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
                            rnn_step=rnn_step, train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers,
-                           Vl_gnn_layers=Vl_gnn_layers, Vh_gnn_layers=Vh_gnn_layers, lagr_init=lagr_init, lr_lagr=lr_lagr)
+                           Vl_gnn_layers=Vl_gnn_layers, Vh_gnn_layers=Vh_gnn_layers, lagr_init=lagr_init, lr_lagr=lr_lagr,
+                           use_rnn=use_rnn, rnn_layers=rnn_layers)
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, use_graphs=True, multi_stream=True,
                                 algo="informarl_lagr")
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2))
-        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3, global_info=True))
+        nc = _n_cells(use_rnn, rnn_layers)
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
+        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3, global_info=True, rnn_layers=nc))
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
         self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
         self.init_Vh_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)

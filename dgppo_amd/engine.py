@@ -43,6 +43,8 @@ class Hyper:
     actor_gnn_layers: int = 2
     Vl_gnn_layers: int = 2
     Vh_gnn_layers: int = 1
+    use_rnn: bool = True              # --no-rnn: networks without a recurrent cell (policy.py:31-32, value.py:38-39)
+    rnn_layers: int = 1               # stacked GRU cells (dgppo/nn/rnn.py:17-29); the DGPPO constraint-value net keeps ONE
     lagr_init: float = 0.78           # InforMARL-Lagrangian: initial multipliers, their step size (informarl_lagr.py:52-53)
     lr_lagr: float = 1e-7
     cost_weight: float = 0.0          # InforMARL: weight of sum(max(cost, 0)) in the stage cost (informarl.py:329)
@@ -52,7 +54,7 @@ class Hyper:
 class RolloutData:
     """Compact rollout record (SURVEY §7 'compact rollout storage'): time-major while collecting, env-major afterwards."""
 
-    def __init__(self, cfg: N.EnvCfg, B: int, T: int, device, stochastic: bool):
+    def __init__(self, cfg: N.EnvCfg, B: int, T: int, device, stochastic: bool, carry_dim: int = nets.HID):
         n, sd = cfg.n_agents, cfg.state_dim
         self.cfg, self.B, self.T, self.stochastic = cfg, B, T, stochastic
         self.has_hits = cfg.is_lidar and cfg.n_obs > 0
@@ -63,7 +65,7 @@ class RolloutData:
         self.obst = z(B, cfg.n_obs, cfg.obst_stride) if cfg.n_obs > 0 else None
         self.action_tm = z(T, B, n, 2)
         self.log_pi_tm = z(T, B, n) if stochastic else None
-        self.rnn_tm = z(T + 1, B, n, nets.HID)
+        self.rnn_tm = z(T + 1, B, n, carry_dim)          # packed actor carry [h_0 | h_1 | ...] of the stacked cells
         self.reward_tm = z(T, B)
         self.cost_tm = z(T, B, n, 2)
         self._env_major = False
@@ -131,7 +133,14 @@ class Engine:
             spec.append(("Vh", "Vh", hyper.Vh_gnn_layers, self.n_cost))
         elif algo == "informarl_lagr":
             spec.append(("Vh", "Vhg", hyper.Vh_gnn_layers, self.n_cost))
-        sizes = [nets.make_layout(kind, cfg.node_dim, layers, n_out).size for _, kind, layers, n_out in spec]
+        # recurrent options (train.py --no-rnn / --rnn-layers): the policy and Vl (and the Lagrangian Vh) stack rnn_layers
+        # cells; DGPPO's constraint-value net is built with the ValueNet default of ONE layer (dgppo.py:83-95) and reads layer
+        # 0 of the actor's carry
+        def rnn_kw(name):
+            if not hyper.use_rnn:
+                return dict(rnn="none", rnn_layers=0)
+            return dict(rnn="gru", rnn_layers=1 if (name == "Vh" and algo == "dgppo") else hyper.rnn_layers)
+        sizes = [nets.make_layout(kind, cfg.node_dim, layers, n_out, **rnn_kw(k)).size for k, kind, layers, n_out in spec]
         offs, tot = [], 0
         for sz in sizes:
             offs.append(tot)
@@ -139,12 +148,13 @@ class Engine:
         self.flat_grads = torch.zeros(tot + 4 * 8, device=device)
         self.n_reduced = tot + 3 * 8
         self.stats = self.flat_grads[tot:tot + 32].view(4, 8)
-        built = {k: nets.Net(kind, cfg, layers, n_out, device, grads=self.flat_grads[o:o + sz])
+        built = {k: nets.Net(kind, cfg, layers, n_out, device, grads=self.flat_grads[o:o + sz], **rnn_kw(k))
                  for (k, kind, layers, n_out), o, sz in zip(spec, offs, sizes)}
         if algo == "informarl_lagr":
             self.lagr = torch.full((cfg.n_agents, self.n_cost), float(hyper.lagr_init), device=device)   # informarl_lagr.py:107
             self.lagr_sums = torch.zeros(cfg.n_agents * self.n_cost, device=device)
         self.policy, self.Vl, self.Vh = built["policy"], built["Vl"], built.get("Vh")
+        self.HC = self.policy.carry_dim              # width of the stored actor carry
         self.opt = {k: OptState(net.layout.size, device) for k, net in self.nets.items()}
         self.arena = nets.Arena(device)
         # allreduce(flat): in-place SUM over the data-parallel ranks of the flat buffer above (dgppo_comm_allreduce_sum_f32 on
@@ -188,8 +198,8 @@ class Engine:
         for t in range(T):
             hits_t = ro.hits_tm[t] if ro.has_hits else None
             feats = self._feats_at(tag, ro.agent_tm[t], hits_t, ro.goal, ro.obst, B)
-            act = self.policy.forward(feats, n_seq=B * n, T=1, h0=ro.rnn_tm[t].view(B * n, nets.HID), tag=tag,
-                                      hs_out=ro.rnn_tm[t + 1].view(B * n, nets.HID), train=False)
+            act = self.policy.forward(feats, n_seq=B * n, T=1, h0=ro.rnn_tm[t].view(B * n, self.HC), tag=tag,
+                                      hs_out=ro.rnn_tm[t + 1].view(B * n, self.HC), train=False)
             a_t = ro.action_tm[t].view(B * n, 2)
             if stochastic:
                 K.policy_head(act["ms"], eps[t], None, a_t, ro.log_pi_tm[t].view(B * n), None, n, 0)
@@ -207,11 +217,11 @@ class Engine:
             # persistent record buffers per (B, kind): eager + capture on the first call, replayed afterwards
             slot = self._ro_cache.setdefault((B, stochastic), {"ro": None, "graph": None, "gen": -1, "calls": 0})
             if slot["ro"] is None:
-                slot["ro"] = RolloutData(cfg, B, T, self.device, stochastic)
+                slot["ro"] = RolloutData(cfg, B, T, self.device, stochastic, self.HC)
             ro = slot["ro"]
             ro._env_major = False
         else:
-            ro = RolloutData(cfg, B, T, self.device, stochastic)
+            ro = RolloutData(cfg, B, T, self.device, stochastic, self.HC)
         OE.env_reset(cfg, seeds, ro.agent_tm[0], ro.goal, ro.obst)
         if ro.has_hits:
             OE.env_step(cfg, ro.agent_tm[0], None, ro.goal, ro.obst, None, self.ray_cos, self.ray_sin, None, ro.hits_tm[0],
@@ -317,14 +327,17 @@ class Engine:
                 continue
             # final carry: actor GRU on next_graph[-1] from rnn_states[-1] (dgppo.py:222-226)
             fin = self._block_feats("fin", ro, e0, Eb, T, 1)
-            h_last = self.arena.get("pre.hlast", Eb * n, H)
-            h_last.view(Eb, n, H).copy_(ro.rnn_states[e0:e0 + Eb, T - 1])
+            HC = self.HC
+            h_last = self.arena.get("pre.hlast", Eb * n, HC)
+            h_last.view(Eb, n, HC).copy_(ro.rnn_states[e0:e0 + Eb, T - 1])
             h0_all = self.arena.get("pre.h0all", Eb, T + 1, n, H)
-            hstar = self.arena.get("pre.hstar", Eb * n, H)
+            hstar = self.arena.get("pre.hstar", Eb * n, HC)
             self.policy.forward(fin, n_seq=Eb * n, T=1, h0=h_last, tag="fin", hs_out=hstar, train=False)
-            h0_all[:, :T].copy_(ro.rnn_states[e0:e0 + Eb])
-            h0_all[:, T].copy_(hstar.view(Eb, n, H))
-            act = self.Vh.forward(feats, n_seq=Eb * (T + 1) * n, T=1, h0=h0_all.view(-1, H), tag="pre", train=False)
+            # the constraint-value net has ONE cell and reads layer 0 of the actor's packed carry (rnn.py:20: rnn_state[0])
+            h0_all[:, :T].copy_(ro.rnn_states[e0:e0 + Eb][..., :H])
+            h0_all[:, T].copy_(hstar.view(Eb, n, HC)[..., :H])
+            act = self.Vh.forward(feats, n_seq=Eb * (T + 1) * n, T=1, h0=h0_all.view(-1, H) if self.hp.use_rnn else None,
+                                  tag="pre", train=False)
             Vh_buf[e0:e0 + Eb].copy_(act["v"].view(Eb, T + 1, n, nh))
         return Vl_buf, Vh_buf
 
@@ -505,7 +518,12 @@ class Engine:
             torch.index_select(tg["Ql"], 0, mb_idx, out=Ql_mb)
             if self.algo == "dgppo":
                 feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=mb_idx32)
-                torch.index_select(det.rnn_states, 0, mb_idx, out=h0_det)
+                if self.HC == H:
+                    torch.index_select(det.rnn_states, 0, mb_idx, out=h0_det)
+                else:                                          # stacked cells: gather the packed carry, keep layer 0
+                    full = A.get("mb.h0_det_full", Eb, T, n, self.HC)
+                    torch.index_select(det.rnn_states, 0, mb_idx, out=full)
+                    h0_det.copy_(full[..., :H])
                 torch.index_select(tg["Qh_det"], 0, mb_idx, out=Qh_det_mb)
             if lagr:
                 torch.index_select(tg["Qh"], 0, mb_idx, out=Qh_mb)
@@ -529,7 +547,7 @@ class Engine:
                     act = self.Vh.forward(feats, n_seq=Eb * C * n, T=hp.rnn_step, h0=None, tag="tr")
                     target = Qh_mb
                 else:             # dgppo.py:296-321: the deterministic rollout with its stored carry
-                    act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det.view(R, H), tag="tr")
+                    act = self.Vh.forward(feats_det, n_seq=R, T=1, h0=h0_det.view(R, H) if hp.use_rnn else None, tag="tr")
                     target = Qh_det_mb
                 dvh = A.get("mb.dvh", R, nh)
                 K.value_loss(act["v"], target.view(R, nh), dvh, self.stats[1])

@@ -61,18 +61,27 @@ def _gru(rng):
             "hz": {"kernel": orthogonal(rng, 64, 64)}, "hn": {"kernel": orthogonal(rng, 64, 64), "bias": z()}}
 
 
-def init_policy(seed: int, node_dim: int, action_dim: int, gnn_layers: int) -> dict:
+def _rnn(rng, rnn_layers: int) -> dict:
+    """RNN_0 of dgppo/nn/rnn.py:14-30: layer l's cell is auto-named GRUCell_{2l+1}"""
+    return {f"GRUCell_{2 * l + 1}": _gru(rng) for l in range(rnn_layers)}
+
+
+def init_policy(seed: int, node_dim: int, action_dim: int, gnn_layers: int, rnn_layers: int = 1) -> dict:
+    """rnn_layers = 0: --no-rnn (no RNN_0 entry)"""
     rng = np.random.default_rng([seed, 1])
+    base = {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "PolicyGNNHead": _mlp(rng)}
+    if rnn_layers > 0:
+        base["RNN_0"] = _rnn(rng, rnn_layers)
     return {"params": {
-        "PolicyNet_0": {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "PolicyGNNHead": _mlp(rng),
-                        "RNN_0": {"GRUCell_1": _gru(rng)}},
+        "PolicyNet_0": base,
         "ScaleHid": _dense(rng, 64, 64, scale=0.01),
         "OutputDenseMean": _dense(rng, 64, action_dim),
         "OutputDenseStdTrans": _dense(rng, 64, action_dim)}}
 
 
-def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, stream: int, global_info: bool = False) -> dict:
+def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, stream: int, global_info: bool = False,
+               rnn_layers: int = 1) -> dict:
     """global_info: DecRStateFn(use_global_info=True) — the head's first Dense takes [x_i | mean_j x_j] (value.py:66-68)"""
     rng = np.random.default_rng([seed, stream])
     return {"params": {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "ValueGNNHead": _mlp(rng, 128 if global_info else 64),
-                       "RNN_0": {"GRUCell_1": _gru(rng)}, "Dense_0": _dense(rng, 64, n_out)}}
+                       **({"RNN_0": _rnn(rng, rnn_layers)} if rnn_layers > 0 else {}), "Dense_0": _dense(rng, 64, n_out)}}

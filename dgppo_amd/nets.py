@@ -41,7 +41,7 @@ class Layout:
         return flat[off:off + math.prod(shape)].view(shape)
 
 
-def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int) -> Layout:
+def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int, rnn: str = "gru", rnn_layers: int = 1) -> Layout:
     """kind: 'policy' | 'Vl' | 'Vh' | 'Vhg' (= DecRStateFn(use_global_info=True): the head sees [x_i | mean_j x_j],
     value.py:66-68, so its first Dense is 128 wide).  Dense kernels are [in, out] like flax."""
     L = Layout()
@@ -58,10 +58,15 @@ def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int) -> Layout
         L.add(f"mlp.b{i}", HID)
         L.add(f"mlp.g{i}", HID)
         L.add(f"mlp.be{i}", HID)
-    L.add("gru.Wi", HID, 3 * HID)   # ir | iz | in
-    L.add("gru.bi", 3 * HID)
-    L.add("gru.Wh", HID, 3 * HID)   # hr | hz | hn
-    L.add("gru.bhn", HID)
+    # recurrent stack (dgppo/nn/rnn.py:14-30): layer 0 keeps the historical names, layer l >= 1 is "gru{l}.*"; rnn == "none"
+    # (--no-rnn: PolicyNet / ValueNet without a cell, policy.py:31-32, value.py:38-39) has no recurrent parameters
+    assert rnn in ("gru", "none"), rnn
+    for l in range(rnn_layers if rnn == "gru" else 0):
+        pre = "gru" if l == 0 else f"gru{l}"
+        L.add(f"{pre}.Wi", HID, 3 * HID)   # ir | iz | in
+        L.add(f"{pre}.bi", 3 * HID)
+        L.add(f"{pre}.Wh", HID, 3 * HID)   # hr | hz | hn
+        L.add(f"{pre}.bhn", HID)
     if kind == "policy":
         L.add("head.Ws", HID, HID)      # ScaleHid
         L.add("head.bs", HID)
@@ -118,12 +123,16 @@ class GraphFeats:
 class Net:
     """One network = flat params + flat grads + prepared GNN weights + forward/backward over a batch of graphs."""
 
-    def __init__(self, kind: str, cfg: N.EnvCfg, gnn_layers: int, n_out: int, device, grads: Optional[torch.Tensor] = None):
+    def __init__(self, kind: str, cfg: N.EnvCfg, gnn_layers: int, n_out: int, device, grads: Optional[torch.Tensor] = None,
+                 rnn: str = "gru", rnn_layers: int = 1):
         """grads: optional caller-owned flat gradient buffer (a slice of the engine's [g_policy | g_Vl | g_Vh | scalars]
-        buffer, so that the data-parallel update all-reduces ALL gradients with one collective)."""
+        buffer, so that the data-parallel update all-reduces ALL gradients with one collective).
+        rnn / rnn_layers: "gru" x L stacked cells (dgppo/nn/rnn.py:14-30; the carry of a row is [L * 64]) or "none"."""
         assert kind in ("policy", "Vl", "Vh", "Vhg")
         self.kind, self.cfg, self.gnn_layers, self.n_out, self.device = kind, cfg, gnn_layers, n_out, device
-        self.layout = make_layout(kind, cfg.node_dim, gnn_layers, n_out)
+        self.rnn, self.rnn_layers = rnn, (rnn_layers if rnn == "gru" else 0)
+        self.carry_dim = HID * max(self.rnn_layers, 1)
+        self.layout = make_layout(kind, cfg.node_dim, gnn_layers, n_out, rnn, rnn_layers)
         self.params = torch.zeros(self.layout.size, device=device)
         if grads is None:
             grads = torch.zeros(self.layout.size, device=device)
@@ -223,14 +232,15 @@ class Net:
             x = xcat
         act["Rh"], act["n_inner"], act["mlp_in"] = Rh, n_inner, x
         gi = A.get(f"{tag}.gi", Rh, 3 * HID)
-        if self.kind == "Vhg":
+        if self.kind == "Vhg" or self.rnn == "none":
             # 128-wide first Dense: the separate Dense / LayerNorm+ReLU kernels (the fused trunk kernel is 64-wide)
             sv = {nm: A.get(f"{tag}.{nm}", Rh, w) for nm, w in (("p1", HID), ("y1", HID), ("st1", 2), ("p2", HID), ("y2", HID), ("st2", 2))}
             K.dense_fwd(x, self.p("mlp.W1"), self.p("mlp.b1"), sv["p1"])
             K.ln_relu_fwd(sv["p1"], self.p("mlp.g1"), self.p("mlp.be1"), sv["y1"], sv["st1"])
             K.dense_fwd(sv["y1"], self.p("mlp.W2"), self.p("mlp.b2"), sv["p2"])
             K.ln_relu_fwd(sv["p2"], self.p("mlp.g2"), self.p("mlp.be2"), sv["y2"], sv["st2"])
-            K.dense_fwd(sv["y2"], self.p("gru.Wi"), self.p("gru.bi"), gi)
+            if self.rnn != "none":
+                K.dense_fwd(sv["y2"], self.p("gru.Wi"), self.p("gru.bi"), gi)
             act.update(sv)
         else:
             # MLP trunk (2 x Dense -> LayerNorm -> ReLU) + GRU input projection: one fused kernel (nn_fused.hip)
@@ -241,15 +251,59 @@ class Net:
                     act[f"p{i}"], act[f"y{i}"], act[f"st{i}"] = saves[3 * (i - 1):3 * i]
             K.mlp_gi_fwd(x, self.p("mlp.W1"), self.p("mlp.b1"), self.p("mlp.g1"), self.p("mlp.be1"), self.p("mlp.W2"),
                          self.p("mlp.b2"), self.p("mlp.g2"), self.p("mlp.be2"), self.p("gru.Wi"), self.p("gru.bi"), gi, saves)
-        hs = hs_out if hs_out is not None else A.get(f"{tag}.hs", Rh, HID)
-        hprev = A.get(f"{tag}.hprev", Rh, HID) if train else None
-        gates = A.get(f"{tag}.gates", Rh, 4 * HID) if train else None
         assert n_seq * T == Rh, (n_seq, T, Rh)
+        L, CD = self.rnn_layers, self.carry_dim
+        if h0 is not None:
+            assert tuple(h0.shape) == (n_seq, CD), (tuple(h0.shape), n_seq, CD)
+        if hs_out is not None:
+            assert tuple(hs_out.shape) == (Rh, CD), (tuple(hs_out.shape), Rh, CD)
+        act["gi"] = gi
+        simple = (self.rnn == "gru" and L == 1)           # the reference default: every fused kernel applies
+        if simple:
+            hs = hs_out if hs_out is not None else A.get(f"{tag}.hs", Rh, HID)
+            hprev = A.get(f"{tag}.hprev", Rh, HID) if train else None
+            gates = A.get(f"{tag}.gates", Rh, 4 * HID) if train else None
+            feat = hs
+            act["hs"], act["hprev"], act["gates"] = hs, hprev, gates
         # one GRU step: the step and the head Dense(s) are row-local -> fused kernel.  Measured (MI355X): policy rollout
         # shape 23.5 vs 34.2 us; for the one-layer value heads at pre-pass sizes the plain GRU kernel + Dense is faster
         # (261 vs 350 us at 524 288 rows), so those keep the separate kernels.
-        fused_tail = (T == 1 and self.kind == "policy")
-        act["gi"], act["hs"], act["hprev"], act["gates"] = gi, hs, hprev, gates
+        fused_tail = (simple and T == 1 and self.kind == "policy")
+        if simple and not fused_tail:
+            K.gru_fwd(gi, self.p("gru.Wh"), self.p("gru.bhn"), h0, hs, hprev, gates, n_seq, T, n_inner)
+        if self.rnn == "none":
+            # no cell: the MLP output is the feature and the carry passes through unchanged (policy.py:29-33)
+            feat = act["y2"]
+            if hs_out is not None:
+                if h0 is not None and T == 1:
+                    hs_out.copy_(h0)
+                else:
+                    hs_out.zero_()
+        elif not simple:
+            # stacked cells (dgppo/nn/rnn.py:17-29): layer l consumes the output sequence of layer l-1; the carry of a row
+            # is [h_0 | h_1 | ...].  Separate kernels per layer (input projection, scan); slices of the packed carry are
+            # copied to contiguous buffers for the scan kernels.
+            x_l = None
+            act["stack"] = []
+            for l in range(L):
+                pre = "gru" if l == 0 else f"gru{l}"
+                gi_l = gi if l == 0 else A.get(f"{tag}.gi{l}", Rh, 3 * HID)
+                if l > 0:
+                    K.dense_fwd(x_l, self.p(f"{pre}.Wi"), self.p(f"{pre}.bi"), gi_l)
+                h0_l = None
+                if h0 is not None:
+                    h0_l = A.get(f"{tag}.h0_{l}", n_seq, HID)
+                    h0_l.copy_(h0[:, l * HID:(l + 1) * HID])
+                hs_l = A.get(f"{tag}.hs{l}", Rh, HID)
+                hprev_l = A.get(f"{tag}.hprev{l}", Rh, HID) if train else None
+                gates_l = A.get(f"{tag}.gates{l}", Rh, 4 * HID) if train else None
+                K.gru_fwd(gi_l, self.p(f"{pre}.Wh"), self.p(f"{pre}.bhn"), h0_l, hs_l, hprev_l, gates_l, n_seq, T, n_inner)
+                if hs_out is not None:
+                    hs_out[:, l * HID:(l + 1) * HID].copy_(hs_l)
+                act["stack"].append(dict(x=x_l, gi=gi_l, hs=hs_l, hprev=hprev_l, gates=gates_l))
+                x_l = hs_l
+            feat = x_l
+        act["feat"] = feat
         if self.kind == "policy":
             u = A.get(f"{tag}.u", Rh, HID) if (train or not fused_tail) else None
             ms = A.get(f"{tag}.ms", Rh, 4)
@@ -257,18 +311,12 @@ class Net:
                 K.gru1_head_fwd(gi, self.p("gru.Wh"), self.p("gru.bhn"), h0, self.p("head.Ws"), self.p("head.bs"),
                                 self.p("head.Wms"), self.p("head.bms"), hs, hprev, gates, u, ms)
             else:
-                K.gru_fwd(gi, self.p("gru.Wh"), self.p("gru.bhn"), h0, hs, hprev, gates, n_seq, T, n_inner)
-                K.dense_fwd(hs, self.p("head.Ws"), self.p("head.bs"), u)
+                K.dense_fwd(feat, self.p("head.Ws"), self.p("head.bs"), u)
                 K.dense_fwd(u, self.p("head.Wms"), self.p("head.bms"), ms)
             act["u"], act["ms"] = u, ms
         else:
             v = A.get(f"{tag}.v", Rh, self.n_out)
-            if fused_tail:
-                K.gru1_head_fwd(gi, self.p("gru.Wh"), self.p("gru.bhn"), h0, self.p("head.Wo"), self.p("head.bo"), None, None,
-                                hs, hprev, gates, None, v)
-            else:
-                K.gru_fwd(gi, self.p("gru.Wh"), self.p("gru.bhn"), h0, hs, hprev, gates, n_seq, T, n_inner)
-                K.dense_fwd(hs, self.p("head.Wo"), self.p("head.bo"), v)
+            K.dense_fwd(feat, self.p("head.Wo"), self.p("head.bo"), v)
             act["v"] = v
         return act
 
@@ -281,26 +329,36 @@ class Net:
         R = G * n
         feats: GraphFeats = act["feats"]
         Ro = G * feats.n_other
-        hs = act["hs"]
+        feat = act["feat"]
         dhs = A.get(f"{tag}.dhs", Rh, HID)
         if self.kind == "policy":
             K.dense_bwd_w(act["u"], dout, self.g("head.Wms"), self.g("head.bms"))
             du = A.get(f"{tag}.du", Rh, HID)
             K.dense_fwd(dout, self.p("head.Wms"), None, du, trans_w=True)
-            K.dense_bwd_w(hs, du, self.g("head.Ws"), self.g("head.bs"))
+            K.dense_bwd_w(feat, du, self.g("head.Ws"), self.g("head.bs"))
             K.dense_fwd(du, self.p("head.Ws"), None, dhs, trans_w=True)
         else:
-            K.dense_bwd_w(hs, dout, self.g("head.Wo"), self.g("head.bo"))
+            K.dense_bwd_w(feat, dout, self.g("head.Wo"), self.g("head.bo"))
             K.dense_fwd(dout, self.p("head.Wo"), None, dhs, trans_w=True)
-        dgi = A.get(f"{tag}.dgi", Rh, 3 * HID)
-        dgh = A.get(f"{tag}.dgh", Rh, 3 * HID)
-        K.gru_bwd(dhs, self.p("gru.Wh"), act["hprev"], act["gates"], dgi, dgh, n_seq, T, n_inner)
-        # hr / hz have no bias (flax GRUCell); only the hn column block carries one
-        K.dense_bwd_w(act["hprev"], dgh[:, :2 * HID], self.g("gru.Wh")[:, :2 * HID], None)
-        K.dense_bwd_w(act["hprev"], dgh[:, 2 * HID:], self.g("gru.Wh")[:, 2 * HID:], self.g("gru.bhn"))
-        K.dense_bwd_w(act["y2"], dgi, self.g("gru.Wi"), self.g("gru.bi"))
-        dy = A.get(f"{tag}.dy", Rh, HID)
-        K.dense_fwd(dgi, self.p("gru.Wi"), None, dy, trans_w=True)
+        if self.rnn == "none":
+            dy = dhs                                   # the head reads the MLP output directly
+        else:
+            stack = act.get("stack") or [dict(x=None, gi=act["gi"], hs=act["hs"], hprev=act["hprev"], gates=act["gates"])]
+            for l in range(len(stack) - 1, -1, -1):
+                st = stack[l]
+                pre = "gru" if l == 0 else f"gru{l}"
+                dgi = A.get(f"{tag}.dgi{l}", Rh, 3 * HID)
+                dgh = A.get(f"{tag}.dgh{l}", Rh, 3 * HID)
+                K.gru_bwd(dhs, self.p(f"{pre}.Wh"), st["hprev"], st["gates"], dgi, dgh, n_seq, T, n_inner)
+                # hr / hz have no bias (flax GRUCell); only the hn column block carries one
+                K.dense_bwd_w(st["hprev"], dgh[:, :2 * HID], self.g(f"{pre}.Wh")[:, :2 * HID], None)
+                K.dense_bwd_w(st["hprev"], dgh[:, 2 * HID:], self.g(f"{pre}.Wh")[:, 2 * HID:], self.g(f"{pre}.bhn"))
+                x_l = act["y2"] if l == 0 else st["x"]
+                K.dense_bwd_w(x_l, dgi, self.g(f"{pre}.Wi"), self.g(f"{pre}.bi"))
+                dx = A.get(f"{tag}.dy" if l == 0 else f"{tag}.dx{l}", Rh, HID)
+                K.dense_fwd(dgi, self.p(f"{pre}.Wi"), None, dx, trans_w=True)
+                dhs = dx                               # gradient of the layer below's output sequence
+            dy = dhs
         x_in = {1: act["mlp_in"], 2: act["y1"]}
         top = act[f"Xa{self.gnn_layers}"]          # output of the last GNN layer (a ReLU output): masks the gradient entering it
         for i in (2, 1):
@@ -380,11 +438,15 @@ class Net:
             self.p(f"mlp.b{i}").copy_(to(hd[f"Dense_{i - 1}"]["bias"]))
             self.p(f"mlp.g{i}").copy_(to(hd[f"LayerNorm_{i - 1}"]["scale"]))
             self.p(f"mlp.be{i}").copy_(to(hd[f"LayerNorm_{i - 1}"]["bias"]))
-        gr = base["RNN_0"]["GRUCell_1"]
-        self.p("gru.Wi").copy_(torch.cat([to(gr[k]["kernel"]) for k in ("ir", "iz", "in")], dim=1))
-        self.p("gru.bi").copy_(torch.cat([to(gr[k]["bias"]) for k in ("ir", "iz", "in")]))
-        self.p("gru.Wh").copy_(torch.cat([to(gr[k]["kernel"]) for k in ("hr", "hz", "hn")], dim=1))
-        self.p("gru.bhn").copy_(to(gr["hn"]["bias"]))
+        # flax auto-names: each layer of RNN.__call__ instantiates the cell class once for the isinstance
+        # probe and once for use (rnn.py:19-20), so layer l's parameters live in GRUCell_{2l+1}
+        for l in range(self.rnn_layers):
+            pre = "gru" if l == 0 else f"gru{l}"
+            gr = base["RNN_0"][f"GRUCell_{2 * l + 1}"]
+            self.p(f"{pre}.Wi").copy_(torch.cat([to(gr[k]["kernel"]) for k in ("ir", "iz", "in")], dim=1))
+            self.p(f"{pre}.bi").copy_(torch.cat([to(gr[k]["bias"]) for k in ("ir", "iz", "in")]))
+            self.p(f"{pre}.Wh").copy_(torch.cat([to(gr[k]["kernel"]) for k in ("hr", "hz", "hn")], dim=1))
+            self.p(f"{pre}.bhn").copy_(to(gr["hn"]["bias"]))
         if self.kind == "policy":
             self.p("head.Ws").copy_(to(t["ScaleHid"]["kernel"]))
             self.p("head.bs").copy_(to(t["ScaleHid"]["bias"]))
@@ -412,18 +474,21 @@ class Net:
         for i in (1, 2):
             head[f"Dense_{i - 1}"] = {"kernel": v(f"mlp.W{i}"), "bias": v(f"mlp.b{i}")}
             head[f"LayerNorm_{i - 1}"] = {"scale": v(f"mlp.g{i}"), "bias": v(f"mlp.be{i}")}
-        Wi, bi, Wh = v("gru.Wi"), v("gru.bi"), v("gru.Wh")
-        gru = {"ir": {"kernel": Wi[:, :64], "bias": bi[:64]}, "iz": {"kernel": Wi[:, 64:128], "bias": bi[64:128]},
-               "in": {"kernel": Wi[:, 128:], "bias": bi[128:]}, "hr": {"kernel": Wh[:, :64]}, "hz": {"kernel": Wh[:, 64:128]},
-               "hn": {"kernel": Wh[:, 128:], "bias": v("gru.bhn")}}
-        rnn = {"GRUCell_1": gru}
+        rnn = {}
+        for l in range(self.rnn_layers):
+            pre = "gru" if l == 0 else f"gru{l}"
+            Wi, bi, Wh = v(f"{pre}.Wi"), v(f"{pre}.bi"), v(f"{pre}.Wh")
+            rnn[f"GRUCell_{2 * l + 1}"] = {
+                "ir": {"kernel": Wi[:, :64], "bias": bi[:64]}, "iz": {"kernel": Wi[:, 64:128], "bias": bi[64:128]},
+                "in": {"kernel": Wi[:, 128:], "bias": bi[128:]}, "hr": {"kernel": Wh[:, :64]}, "hz": {"kernel": Wh[:, 64:128]},
+                "hn": {"kernel": Wh[:, 128:], "bias": v(f"{pre}.bhn")}}
         if self.kind == "policy":
             Wms, bms = v("head.Wms"), v("head.bms")
             k = self.n_out
             return {"params": {
-                "PolicyNet_0": {"GraphTransformerGNN_0": gnn, "PolicyGNNHead": head, "RNN_0": rnn},
+                "PolicyNet_0": dict({"GraphTransformerGNN_0": gnn, "PolicyGNNHead": head}, **({"RNN_0": rnn} if rnn else {})),
                 "ScaleHid": {"kernel": v("head.Ws"), "bias": v("head.bs")},
                 "OutputDenseMean": {"kernel": Wms[:, :k], "bias": bms[:k]},
                 "OutputDenseStdTrans": {"kernel": Wms[:, k:], "bias": bms[k:]}}}
-        return {"params": {"GraphTransformerGNN_0": gnn, "ValueGNNHead": head, "RNN_0": rnn,
-                           "Dense_0": {"kernel": v("head.Wo"), "bias": v("head.bo")}}}
+        return {"params": dict({"GraphTransformerGNN_0": gnn, "ValueGNNHead": head, "Dense_0": {"kernel": v("head.Wo"), "bias": v("head.bo")}},
+                               **({"RNN_0": rnn} if rnn else {}))}

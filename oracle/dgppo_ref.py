@@ -43,7 +43,7 @@ def values_Vl(trees, ocfg, ro):
     g = graphs_of(ocfg, ro["agent"], ro["goal"], ro["obst"], ro["hits"])
     B, T1 = ro["agent"].shape[:2]
     with torch.no_grad():
-        h = torch.zeros(B, 1, 64)
+        h = torch.zeros(B, 1, T.carry_width(trees["Vl"]))
         vs = []
         for t in range(T1):
             v, h = T.value_Vl(trees["Vl"], _sel(g, t=t), h, n)
@@ -76,18 +76,19 @@ def values(trees, ocfg, ro, stochastic):
     g = graphs_of(ocfg, ro["agent"], ro["goal"], ro["obst"], ro["hits"])
     B, T1 = ro["agent"].shape[:2]
     Tn = T1 - 1
-    rnn = torch.from_numpy(ro["rnn_states"])                     # [B,T,n,64] stored carry
+    rnn = torch.from_numpy(ro["rnn_states"])                     # [B,T,n,L*64] stored (packed) carry
     with torch.no_grad():
         Vl = None
         if stochastic:
-            h = torch.zeros(B, 1, 64)
+            h = torch.zeros(B, 1, T.carry_width(trees["Vl"]))
             vs = []
             for t in range(T1):                                  # scan_Vl + final value on next_graph[-1] (dgppo.py:204-216)
                 v, h = T.value_Vl(trees["Vl"], _sel(g, t=t), h, n)
                 vs.append(v)
             Vl = torch.stack(vs, 1).numpy()
         flat = {k: v[:, :Tn].reshape((B * Tn,) + v.shape[2:]) for k, v in g.items()}
-        Vh, _ = T.value_Vh(trees["Vh"], flat, rnn.reshape(B * Tn, n, 64), n)          # dgppo.py:219-220
+        HC = rnn.shape[-1]                                       # packed actor carry; the one-cell Vh reads layer 0 (rnn.py:20)
+        Vh, _ = T.value_Vh(trees["Vh"], flat, rnn.reshape(B * Tn, n, HC), n)          # dgppo.py:219-220
         Vh = Vh.view(B, Tn, n, -1)
         _, hstar = T.policy_net(trees["policy"], _sel(g, t=Tn), rnn[:, -1], n)        # dgppo.py:222-226
         Vh_fin, _ = T.value_Vh(trees["Vh"], _sel(g, t=Tn), hstar, n)
@@ -120,7 +121,7 @@ def minibatch_losses(trees, ocfg, ro, det, tg, idx, hp, eps_hat):
     gc = {k: chunk(v) for k, v in g.items()}
     out = {}
     # ---- Vl
-    h = torch.zeros(Eb * C, 1, 64)
+    h = torch.zeros(Eb * C, 1, T.carry_width(trees["Vl"]))
     vs = []
     for tau in range(rs):
         v, h = T.value_Vl(trees["Vl"], _sel(gc, t=tau), h, n)
@@ -134,13 +135,13 @@ def minibatch_losses(trees, ocfg, ro, det, tg, idx, hp, eps_hat):
         gd = graphs_of(ocfg, det["agent"][idx][:, :Tn], sub(det, "goal"), sub(det, "obst"),
                        None if det["hits"] is None else det["hits"][idx][:, :Tn])
         flat = {k: v.reshape((Eb * Tn,) + v.shape[2:]) for k, v in gd.items()}
-        vh, _ = T.value_Vh(trees["Vh"], flat, torch.from_numpy(det["rnn_states"][idx]).reshape(Eb * Tn, n, 64), n)
+        vh, _ = T.value_Vh(trees["Vh"], flat, torch.from_numpy(det["rnn_states"][idx]).reshape(Eb * Tn, n, -1), n)
         loss_Vh = (0.5 * (vh.view(Eb, Tn, n, -1) - torch.from_numpy(tg["Qh_det"][idx])) ** 2).mean()
         loss_Vh.backward()
         out["Vh/loss_Vh"] = float(loss_Vh.detach())
     # ---- policy
     a_in = chunk(torch.from_numpy(ro["actions"][idx]))
-    h = torch.zeros(Eb * C, n, 64)
+    h = torch.zeros(Eb * C, n, T.carry_width(trees["policy"]))
     lps, ents = [], []
     for tau in range(rs):
         lp, ent, h = T.policy_eval(trees["policy"], _sel(gc, t=tau), a_in[:, tau], h, n, eps_hat)
@@ -168,7 +169,7 @@ def values_Vh_lagr(trees, ocfg, ro):
     g = graphs_of(ocfg, ro["agent"], ro["goal"], ro["obst"], ro["hits"])
     B, T1 = ro["agent"].shape[:2]
     with torch.no_grad():
-        h = torch.zeros(B, n, 64)
+        h = torch.zeros(B, n, T.carry_width(trees["Vh"]))
         vs = []
         for t in range(T1):
             v, h = T.value_Vh(trees["Vh"], _sel(g, t=t), h, n, global_info=True)
@@ -197,7 +198,7 @@ def minibatch_losses_lagr(trees, ocfg, ro, tg, idx, hp, eps_hat):
                   None if ro["hits"] is None else ro["hits"][idx][:, :Tn])
     Eb = len(idx)
     gc = {k: v.reshape((Eb * C, rs) + v.shape[2:]) for k, v in g.items()}
-    h = torch.zeros(Eb * C, n, 64)
+    h = torch.zeros(Eb * C, n, T.carry_width(trees["Vh"]))
     vs = []
     for tau in range(rs):
         v, h = T.value_Vh(trees["Vh"], _sel(gc, t=tau), h, n, global_info=True)
@@ -219,7 +220,7 @@ def log_pi_full_episode(trees, ocfg, ro, idx, eps_hat):
     g = graphs_of(ocfg, ro["agent"][idx][:, :Tn], sub(ro, "goal"), sub(ro, "obst"),
                   None if ro["hits"] is None else ro["hits"][idx][:, :Tn])
     acts = torch.from_numpy(ro["actions"][idx])
-    h = torch.zeros(len(idx), n, 64)
+    h = torch.zeros(len(idx), n, T.carry_width(trees["policy"]))
     lps = []
     with torch.no_grad():
         for t in range(Tn):

@@ -91,29 +91,32 @@ def init_gru(gen, f_in=64, hid=64):
     }
 
 
-def init_policy(seed: int, node_dim: int, action_dim: int = 2, gnn_layers: int = 2):
-    """actor.pkl tree of SURVEY A.9 (dgppo/algo/module/policy.py:20-78,149-180)."""
+def _init_rnn(gen, rnn_layers: int):
+    return {f"GRUCell_{2 * l + 1}": init_gru(gen) for l in range(rnn_layers)}
+
+
+def init_policy(seed: int, node_dim: int, action_dim: int = 2, gnn_layers: int = 2, rnn_layers: int = 1):
+    """actor.pkl tree of SURVEY A.9 (dgppo/algo/module/policy.py:20-78,149-180).  rnn_layers = 0: --no-rnn."""
     gen = torch.Generator().manual_seed(seed)
+    base = {"GraphTransformerGNN_0": init_gnn(gen, node_dim, gnn_layers), "PolicyGNNHead": init_mlp(gen, 64)}
+    if rnn_layers > 0:
+        base["RNN_0"] = _init_rnn(gen, rnn_layers)
     return {"params": {
-        "PolicyNet_0": {
-            "GraphTransformerGNN_0": init_gnn(gen, node_dim, gnn_layers),
-            "PolicyGNNHead": init_mlp(gen, 64),
-            "RNN_0": {"GRUCell_1": init_gru(gen)},
-        },
+        "PolicyNet_0": base,
         "ScaleHid": _dense(gen, 64, 64, scale=0.01),
         "OutputDenseMean": _dense(gen, 64, action_dim),
         "OutputDenseStdTrans": _dense(gen, 64, action_dim),
     }}
 
 
-def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, global_info: bool = False):
+def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, global_info: bool = False, rnn_layers: int = 1):
     """Vl.pkl / Vh.pkl trees (dgppo/algo/module/value.py:15-79).  global_info: DecRStateFn(use_global_info=True), whose
     head sees [x_i | mean_j x_j] (value.py:66-68), i.e. a 128-wide first Dense."""
     gen = torch.Generator().manual_seed(seed)
     return {"params": {
         "GraphTransformerGNN_0": init_gnn(gen, node_dim, gnn_layers),
         "ValueGNNHead": init_mlp(gen, 128 if global_info else 64),
-        "RNN_0": {"GRUCell_1": init_gru(gen)},
+        **({"RNN_0": _init_rnn(gen, rnn_layers)} if rnn_layers > 0 else {}),
         "Dense_0": _dense(gen, 64, n_out),
     }}
 
@@ -168,6 +171,28 @@ def gru_cell(p, h, x):
     z = torch.sigmoid(dense(p["iz"], x) + dense(p["hz"], h))
     n = torch.tanh(dense(p["in"], x) + r * dense(p["hn"], h))
     return (1.0 - z) * n + z * h
+
+
+def rnn_apply(p_rnn, h, x):
+    """RNN (dgppo/nn/rnn.py:14-30) with GRU cells.  p_rnn = the params of 'RNN_0' ({'GRUCell_{2l+1}': ...}: every layer
+    instantiates the cell class once for the isinstance probe and once for use) or None (--no-rnn: the net
+    has no cell and the carry passes through, policy.py:29-33).  h [..., L*64] packed carry -> (output, new packed carry)."""
+    if p_rnn is None:
+        return x, h
+    names = sorted(p_rnn.keys(), key=lambda k: int(k.split("_")[1]))
+    hs = []
+    for l, name in enumerate(names):
+        hl = gru_cell(p_rnn[name], h[..., l * 64:(l + 1) * 64], x)
+        hs.append(hl)
+        x = hl
+    return x, torch.cat(hs, dim=-1)
+
+
+def carry_width(tree) -> int:
+    """width of the packed carry of a policy / value tree: 64 per stacked cell (64 of pass-through zeros without a cell)"""
+    p = tree["params"]
+    p = p.get("PolicyNet_0", p)
+    return 64 * max(len(p.get("RNN_0", {})), 1)
 
 
 def segment_softmax(logits: Tensor, seg: Tensor, num_segments: int) -> Tensor:
@@ -228,8 +253,7 @@ def policy_net(pp, graph, h, n_agents):
     p = pp["params"]["PolicyNet_0"]
     x = gnn(p["GraphTransformerGNN_0"], graph, n_agents)
     x = mlp(p["PolicyGNNHead"], x)
-    new_h = gru_cell(p["RNN_0"]["GRUCell_1"], h, x)
-    return new_h, new_h
+    return rnn_apply(p.get("RNN_0"), h, x)
 
 
 def policy_dist(pp, graph, h, n_agents):
@@ -298,8 +322,8 @@ def value_Vl(vp, graph, h, n_agents):
     x = gnn(p["GraphTransformerGNN_0"], graph, n_agents)
     x = x.mean(dim=1, keepdim=True)
     x = mlp(p["ValueGNNHead"], x)
-    new_h = gru_cell(p["RNN_0"]["GRUCell_1"], h, x)
-    return dense(p["Dense_0"], new_h)[:, 0, 0], new_h
+    x, new_h = rnn_apply(p.get("RNN_0"), h, x)
+    return dense(p["Dense_0"], x)[:, 0, 0], new_h
 
 
 def value_Vh(vp, graph, h, n_agents, global_info: bool = False):
@@ -310,8 +334,8 @@ def value_Vh(vp, graph, h, n_agents, global_info: bool = False):
     if global_info:
         x = torch.cat([x, x.mean(dim=1, keepdim=True).expand(-1, n_agents, -1)], dim=-1)
     x = mlp(p["ValueGNNHead"], x)
-    new_h = gru_cell(p["RNN_0"]["GRUCell_1"], h, x)
-    return dense(p["Dense_0"], new_h), new_h
+    x, new_h = rnn_apply(p.get("RNN_0"), h, x)
+    return dense(p["Dense_0"], x), new_h
 
 
 def graph_to_torch(g: Dict[str, np.ndarray]) -> Dict[str, Tensor]:

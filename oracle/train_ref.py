@@ -33,7 +33,7 @@ def rollout(ocfg, trees, seeds, T_steps, stochastic, rng: np.random.Generator):
     has_hits = ocfg.is_lidar and ocfg.n_obs > 0
     hits = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)[0] if has_hits else None
     B = agent.shape[0]
-    h = torch.zeros(B, n, 64)
+    h = torch.zeros(B, n, T.carry_width(trees["policy"]))
     rec = {k: [] for k in ("agent", "hits", "actions", "log_pis", "rnn", "rewards", "costs")}
     for t in range(T_steps):
         g = T.graph_to_torch(E.get_graph(ocfg, agent, goal, obst if not ocfg.is_lidar else obst, hits))

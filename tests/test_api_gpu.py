@@ -309,3 +309,46 @@ def test_informarl_lagr_algo_round_trip(cuda, tmp_path):
     algo2.load(str(tmp_path), 3)
     for k in ("policy", "Vl", "Vh"):
         assert torch.equal(algo2.engine.nets[k].params, algo.engine.nets[k].params)
+
+
+def test_epoch_ppo_runs_that_many_passes(cuda):
+    """epoch_ppo > 1 (dgppo.py:154-172): every epoch is a full pass over reshuffled minibatches with recomputed targets —
+    the optimisers must have stepped epoch_ppo * n_minibatches times."""
+    from dgppo.env import make_env
+    env = make_env("MPESpread", 3, max_step=16, num_obs=2)
+    from dgppo.algo import make_algo
+    algo = make_algo(algo="dgppo", env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+                     action_dim=env.action_dim, n_agents=env.num_agents, batch_size=4 * 16, rnn_step=8, train_steps=10, seed=1,
+                     epoch_ppo=3)
+    assert algo.config["epoch_ppo"] == 3
+    info = algo.update(algo.collect(None, np.arange(1, 17)), 0)
+    assert all(np.isfinite(v) for v in info.values())
+    for k in ("policy", "Vl", "Vh"):
+        assert float(algo.engine.opt[k].state[2]) == 3 * (16 // 4)
+
+
+@pytest.mark.parametrize("flags,shape", [(dict(use_rnn=False), (1, 3, 1, 64)), (dict(rnn_layers=2), (2, 3, 1, 64))])
+def test_rnn_option_flags_through_the_algo_surface(cuda, flags, shape):
+    """--no-rnn / --rnn-layers (train.py:30-33): carries have the reference's (n_layers, n_agents, n_carries, 64) shape at
+    the API, act / collect / update run, and --use-lstm is refused loudly."""
+    from dgppo.algo import make_algo
+    from dgppo.env import make_env
+    env = make_env("LidarSpread", 3, num_obs=1, max_step=16)
+    kw = dict(env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim, action_dim=env.action_dim,
+              n_agents=env.num_agents, batch_size=128, rnn_step=8, train_steps=10, seed=1)
+    algo = make_algo(algo="dgppo", **kw, **flags)
+    assert algo.init_rnn_state.shape == shape
+    g = env.reset(3)
+    a, h = algo.act(g, algo.init_rnn_state)
+    assert a.shape == (3, 2) and h.shape == shape
+    if flags.get("use_rnn", True):
+        a2, h2 = algo.act(g, h)
+        assert not torch.equal(h, h2)
+    else:
+        assert float(h.abs().max()) == 0.0
+    ro = algo.collect(None, np.arange(1, 17))
+    assert ro.rnn_states.shape == (16, 16) + shape
+    info = algo.update(ro, 0)
+    assert all(np.isfinite(v) for v in info.values())
+    with pytest.raises(NotImplementedError, match="lstm"):
+        make_algo(algo="dgppo", **kw, use_lstm=True)

@@ -21,15 +21,16 @@ def _np_rollout(ro):
                 log_pis=c(ro.log_pis), rnn_states=c(ro.rnn_states.contiguous()), rewards=c(ro.rewards), costs=c(ro.costs))
 
 
-def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step, **engine_kw):
+def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step, use_rnn=True, rnn_layers=1, **engine_kw):
     from dgppo_amd import _native as N, engine as EN, init
     kind = N.ENV_KINDS[kind_name]
     cfg = N.make_env_cfg(kind, n, n_obs)
     ocfg = E.EnvCfg(kind, n_agents=n, n_obs=n_obs)
-    hp = EN.Hyper(batch_size=batch_size, rnn_step=rnn_step, train_steps=100)
+    hp = EN.Hyper(batch_size=batch_size, rnn_step=rnn_step, train_steps=100, use_rnn=use_rnn, rnn_layers=rnn_layers)
     eng = EN.Engine(cfg, hp, cuda, T=T_, **engine_kw)
-    trees = {"policy": init.init_policy(0, cfg.node_dim, 2, 2), "Vl": init.init_value(0, cfg.node_dim, 1, 2, 2),
-             "Vh": init.init_value(0, cfg.node_dim, 2, 1, 3)}
+    nc = rnn_layers if use_rnn else 0
+    trees = {"policy": init.init_policy(0, cfg.node_dim, 2, 2, nc), "Vl": init.init_value(0, cfg.node_dim, 1, 2, 2, rnn_layers=nc),
+             "Vh": init.init_value(0, cfg.node_dim, 2, 1, 3, rnn_layers=min(nc, 1))}
     rng = np.random.default_rng(11)
     jitter = lambda tr: T.tree_map(lambda a: torch.from_numpy(a + 0.05 * rng.standard_normal(a.shape).astype(np.float32)), tr)
     trees = {k: jitter(v) for k, v in trees.items()}
@@ -510,3 +511,45 @@ def test_informarl_lagr_targets_gradients_and_multipliers(cuda):
     assert not np.array_equal(got, lagr0)
     np.testing.assert_allclose(got, want, atol=2e-6)
     assert abs(info["policy/lagr_mean"] - float(want.mean())) < 1e-5
+
+
+@pytest.mark.parametrize("use_rnn,rnn_layers", [(False, 1), (True, 2)])
+def test_rnn_options_targets_and_gradients(cuda, use_rnn, rnn_layers):
+    """train.py --no-rnn and --rnn-layers 2 through the whole engine (rollout with the packed carry, value pre-passes where
+    the one-cell constraint-value net reads layer 0 of the actor's carry, GAE, first-minibatch gradients) vs the oracle."""
+    kind, n, n_obs, B, T_, rs, bs = "LidarSpread", 3, 2, 4, 8, 4, 16
+    cfg, ocfg, hp, eng, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs, use_rnn=use_rnn, rnn_layers=rnn_layers,
+                                       multi_stream=True)
+    assert eng.HC == 64 * (rnn_layers if use_rnn else 1)
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    ro = eng.rollout(seeds, True, noise_seed=3)
+    det = eng.rollout(seeds + 1000, False)
+    ro.finalize(); det.finalize()
+    assert ro.rnn_states.shape == (B, T_, n, eng.HC)
+    if not use_rnn:
+        assert float(ro.rnn_states.abs().max()) == 0.0            # no cell: the zero carry passes through
+    step = 10
+    tg = eng.targets(ro, det, step)
+    hpd = dict(gamma=hp.gamma, gae_lambda=hp.gae_lambda, alpha=hp.alpha, cbf_eps=hp.cbf_eps, rnn_step=rs,
+               clip_eps=hp.clip_eps, coef_ent=hp.coef_ent)
+    r, d = _np_rollout(ro), _np_rollout(det)
+    leaf = {k: T.tree_map(lambda t: t.clone().requires_grad_(), v) for k, v in trees.items()}
+    w = eng.cbf_weight_at(step)
+    wt = R.targets(leaf, ocfg, r, d, hpd, w)
+    for k in ("Vl", "Vh", "Vh_det", "Ql", "Qh", "Qh_det"):
+        _close(tg[k], wt[k], k)
+    _check_advantage(tg, wt, ocfg.dt, hp.alpha, hp.cbf_eps, w, f"rnn={use_rnn} x{rnn_layers}")
+    perm = np.array([2, 0, 3, 1])
+    grads = {}
+
+    def hook(name, net, mb):
+        if mb == 0:
+            grads[name] = net.to_tree(net.grads)
+    eng.grad_hook = hook
+    Eb = bs // T_
+    tg_np = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in tg.items()}
+    R.minibatch_losses(leaf, ocfg, r, d, tg_np, perm[:Eb], hpd, eng.eps_hat.cpu())
+    info = eng.update(ro, det, step, perm)
+    torch.cuda.synchronize()
+    _check_first_minibatch_grads(leaf, grads, ("Vl", "Vh", "policy"))
+    assert info["policy/has_nan"] == 0.0

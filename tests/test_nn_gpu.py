@@ -676,3 +676,83 @@ def test_Vh_global_info_forward_backward(cuda, kind, n, n_obs):
     net.backward(act, dv)
     torch.cuda.synchronize()
     _grad_tree_close(net, lt, 3e-5)
+
+
+@pytest.mark.parametrize("rnn_layers", [0, 2, 3])
+def test_policy_and_Vl_with_rnn_options(cuda, rnn_layers):
+    """--no-rnn (rnn_layers = 0 here: no cell, the MLP output feeds the head, the carry passes through: policy.py:29-33)
+    and stacked GRU cells (--rnn-layers L: layer l consumes layer l-1's output, packed carry [h_0 | h_1 | ...],
+    dgppo/nn/rnn.py:17-29): chunk scan with a NON-zero initial carry, forward and backward against the oracle."""
+    from dgppo_amd import nets, ops_nn as K_
+    kind, n, n_obs, n_env, T_ = E.LIDAR_SPREAD, 3, 2, 3, 5
+    cfg, ocfg, ag, goal, obst, hi, gr = _scene(kind, n, n_obs, n_env, T_, seed=17)
+    gen = torch.Generator().manual_seed(5 + rnn_layers)
+    jit = lambda tr: T.tree_map(lambda t: t + 0.05 * torch.randn(t.shape, generator=gen), tr)
+    ptree = jit(T.init_policy(1, cfg.node_dim, rnn_layers=rnn_layers))
+    ptree["params"]["ScaleHid"]["kernel"] = T.orthogonal(gen, 64, 64, 0.5)
+    vtree = jit(T.init_value(2, cfg.node_dim, 1, 2, rnn_layers=rnn_layers))
+    kw = dict(rnn="gru", rnn_layers=rnn_layers) if rnn_layers > 0 else dict(rnn="none", rnn_layers=0)
+    CD = 64 * max(rnn_layers, 1)
+    feats = _feats(cfg, ag, goal, obst, hi, cuda)
+    g_t = T.graph_to_torch(gr)
+    gsel = lambda t: {k: v.view((n_env, T_) + v.shape[1:])[:, t] for k, v in g_t.items()}
+    G = n_env * T_
+    # ---- policy
+    pol = nets.Net("policy", cfg, 2, 2, cuda, **kw)
+    assert pol.carry_dim == CD
+    pol.load_tree(ptree)
+    back = pol.to_tree()
+    assert set(dict(T.tree_leaves(back))) == set(dict(T.tree_leaves(ptree)))
+    h0 = 0.3 * torch.randn(n_env, n, CD, generator=gen)
+    act = pol.forward(feats, n_seq=n_env * n, T=T_, h0=h0.reshape(n_env * n, CD).to(cuda))
+    lt = _leafify(ptree)
+    rng = torch.Generator().manual_seed(9)
+    a_in = torch.tanh(torch.randn(n_env, T_, n, 2, generator=rng))
+    eps_hat = torch.randn(n, 2, generator=rng)
+    h = h0.clone()
+    lps, ents = [], []
+    for t in range(T_):
+        lp, ent, h = T.policy_eval(lt, gsel(t), a_in[:, t], h, n, eps_hat)
+        lps.append(lp); ents.append(ent)
+    lp_w, ent_w = torch.stack(lps, 1), torch.stack(ents, 1)
+    R = G * n
+    lp_old = lp_w.detach() + 0.2 * torch.randn(n_env, T_, n, generator=rng)
+    adv = torch.randn(n_env, T_, n, generator=rng)
+    rho = torch.exp(lp_w - lp_old)
+    (torch.maximum(-rho * adv, -torch.clamp(rho, 0.75, 1.25) * adv).mean() - 0.01 * ent_w.mean()).backward()
+    lp = torch.empty(R, device=cuda); ent = torch.empty(R, device=cuda)
+    dms = torch.empty(R, 4, device=cuda); stats = torch.zeros(8, device=cuda)
+    K_.policy_head(act["ms"], eps_hat.to(cuda), a_in.reshape(R, 2).to(cuda), None, lp, ent, n, 2,
+                   lp_old.reshape(R).to(cuda), adv.reshape(R).to(cuda), dms, stats, 0.25, 0.01)
+    _close(lp.view(n_env, T_, n), lp_w, 1e-5, "policy log_pi")
+    pol.zero_grads()
+    pol.backward(act, dms)
+    torch.cuda.synchronize()
+    _grad_tree_close(pol, lt, 3e-5)
+    # one step with hs_out: the packed carry that the rollout stores
+    one = _feats(cfg, np.ascontiguousarray(ag[:, :1]), goal, obst, np.ascontiguousarray(hi[:, :1]) if hi is not None else None, cuda, tag="o")
+    hs_out = torch.full((n_env * n, CD), float("nan"), device=cuda)
+    pol.forward(one, n_seq=n_env * n, T=1, h0=h0.reshape(n_env * n, CD).to(cuda), hs_out=hs_out, train=False, tag="o")
+    with torch.no_grad():
+        _, h1 = T.policy_mode(ptree, gsel(0), h0, n)
+    _close(hs_out.view(n_env, n, CD), h1, 1e-5, "carry after one step")
+    # ---- Vl (one sequence per env, n_inner = 1)
+    vl = nets.Net("Vl", cfg, 2, 1, cuda, **kw)
+    vl.load_tree(vtree)
+    act = vl.forward(feats, n_seq=n_env, T=T_, h0=None)
+    lv = _leafify(vtree)
+    h = torch.zeros(n_env, 1, CD)
+    vs = []
+    for t in range(T_):
+        v, h = T.value_Vl(lv, gsel(t), h, n)
+        vs.append(v)
+    v_w = torch.stack(vs, 1)
+    _close(act["v"].view(n_env, T_), v_w, 1e-5, "Vl")
+    target = torch.randn(n_env, T_, generator=gen)
+    (0.5 * (v_w - target) ** 2).mean().backward()
+    dv = torch.empty(G, 1, device=cuda)
+    K_.value_loss(act["v"], target.reshape(-1, 1).to(cuda), dv, torch.zeros(8, device=cuda))
+    vl.zero_grads()
+    vl.backward(act, dv)
+    torch.cuda.synchronize()
+    _grad_tree_close(vl, lv, 3e-5)
