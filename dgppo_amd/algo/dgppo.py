@@ -59,10 +59,7 @@ def _unflatten_tree(v, B, T):
 
 
 def _check_rnn_options(use_rnn: bool, use_lstm: bool, rnn_layers: int):
-    """GRU cells (any number of stacked layers, dgppo/nn/rnn.py:17-29) and --no-rnn are built; the LSTM cell is not"""
-    if use_rnn and use_lstm:
-        raise NotImplementedError("--use-lstm: this build implements the GRU cell (the reference default) and --no-rnn; "
-                                  "flax LSTMCell (dgppo/nn/rnn.py:22-24) is not built")
+    """GRU or LSTM cells, any number of stacked layers (dgppo/nn/rnn.py:17-29), or --no-rnn"""
     assert rnn_layers >= 1
 
 
@@ -89,36 +86,41 @@ class DGPPO(Algorithm):
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
                            rnn_step=rnn_step, alpha=alpha, cbf_eps=cbf_eps, cbf_weight=cbf_weight, cbf_schedule=cbf_schedule,
                            train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers, Vl_gnn_layers=Vl_gnn_layers,
-                           Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers)
+                           Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
                                 use_graphs=True, multi_stream=True)
-        nc = _n_cells(use_rnn, rnn_layers)
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
+        nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))
         # the constraint-value net is built with ValueNet's default of one cell (dgppo.py:83-95)
         self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3, rnn_layers=min(nc, 1)))
         # np.random.randint(0, 102400) at trace time in the reference (distribution.py:40)
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
         # (n_rnn_layers, n_agents, n_carries, rnn_state_dim), zeros (informarl.py:115-124)
-        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        # (n_rnn_layers, n_agents, n_carries, 64): one carry for GRU / no cell, (c, h) for LSTM (informarl.py:115-124)
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 2 if self.hp.use_lstm else 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
         self._single = nets.Arena(self.device)
 
     # ---- carry layout: the reference's (n_layers, n_agents, n_carries = 1, 64) <-> the engine's packed rows [n, L * 64] ----
+    def _carry_dims(self):
+        nc = 2 if self.hp.use_lstm else 1
+        return max(self.engine.HC // (nets.HID * nc), 1), nc
+
     def _pack_carry(self, rnn_state) -> torch.Tensor:
-        n, HC = self.n_agents, self.engine.HC
-        x = torch.as_tensor(rnn_state, dtype=torch.float32, device=self.device).reshape(-1, n, nets.HID)
-        x = x[:max(HC // nets.HID, 1)]
-        return x.permute(1, 0, 2).reshape(n, HC).contiguous()
+        """(L, n, n_carries, 64) -> packed rows [n, L * n_carries * 64] (per layer: carry 0, carry 1)"""
+        n, (L, nc) = self.n_agents, self._carry_dims()
+        x = torch.as_tensor(rnn_state, dtype=torch.float32, device=self.device).reshape(-1, n, nc, nets.HID)[:L]
+        return x.permute(1, 0, 2, 3).reshape(n, self.engine.HC).contiguous()
 
     def _unpack_carry(self, rows: torch.Tensor) -> torch.Tensor:
-        """[..., n, L * 64] -> [..., L, n, 1, 64]"""
-        n, L = self.n_agents, max(self.engine.HC // nets.HID, 1)
+        """[..., n, L * n_carries * 64] -> [..., L, n, n_carries, 64]"""
+        n, (L, nc) = self.n_agents, self._carry_dims()
         lead = rows.shape[:-2]
-        x = rows.reshape(lead + (n, L, nets.HID))
-        perm = tuple(range(len(lead))) + (len(lead) + 1, len(lead), len(lead) + 2)
-        return x.permute(perm).unsqueeze(-2)
+        x = rows.reshape(lead + (n, L, nc, nets.HID))
+        k = len(lead)
+        return x.permute(tuple(range(k)) + (k + 1, k, k + 2, k + 3))
 
     # ---- reference properties ----
     @property

@@ -34,15 +34,15 @@ class InforMARL(DGPPO):
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, batch_size=batch_size,
                            rnn_step=rnn_step, train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers,
                            Vl_gnn_layers=Vl_gnn_layers, cost_weight=cost_weight, cost_schedule=cost_schedule,
-                           use_rnn=use_rnn, rnn_layers=rnn_layers)
+                           use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
                                 use_graphs=True, multi_stream=True, algo="informarl")
-        nc = _n_cells(use_rnn, rnn_layers)
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
+        nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
-        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 2 if self.hp.use_lstm else 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
         self._single = nets.Arena(self.device)
 
@@ -115,15 +115,15 @@ class HCBFCRPO(InforMARL):
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
                            rnn_step=rnn_step, alpha=alpha, cbf_eps=cbf_eps, cbf_weight=cbf_weight, cbf_schedule=cbf_schedule,
                            train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers, Vl_gnn_layers=Vl_gnn_layers,
-                           Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers)
+                           Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
                                 use_graphs=True, multi_stream=True, algo="hcbfcrpo")
-        nc = _n_cells(use_rnn, rnn_layers)
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
+        nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
-        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 2 if self.hp.use_lstm else 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
         self._single = nets.Arena(self.device)
 
@@ -157,16 +157,17 @@ class InforMARLLagr(InforMARL):
                            max_grad_norm=max_grad_norm, lr_actor=lr_actor, lr_Vl=lr_Vl, lr_Vh=lr_Vh, batch_size=batch_size,
                            rnn_step=rnn_step, train_steps=int(train_steps), actor_gnn_layers=actor_gnn_layers,
                            Vl_gnn_layers=Vl_gnn_layers, Vh_gnn_layers=Vh_gnn_layers, lagr_init=lagr_init, lr_lagr=lr_lagr,
-                           use_rnn=use_rnn, rnn_layers=rnn_layers)
+                           use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, use_graphs=True, multi_stream=True,
                                 algo="informarl_lagr")
-        nc = _n_cells(use_rnn, rnn_layers)
-        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc))
-        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc))
-        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3, global_info=True, rnn_layers=nc))
+        nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
+        self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
+        self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))
+        self.engine.Vh.load_tree(INIT.init_value(seed, node_dim, env.n_cost, Vh_gnn_layers, 3, global_info=True, rnn_layers=nc,
+                                                 lstm=lstm))
         self.engine.set_entropy_noise(int(np.random.randint(0, 102400)))
-        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
+        self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 2 if self.hp.use_lstm else 1, nets.HID, device=self.device)
         self.init_Vh_rnn_state = torch.zeros(rnn_layers, n_agents, 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
         self._single = nets.Arena(self.device)

@@ -44,7 +44,8 @@ class Hyper:
     Vl_gnn_layers: int = 2
     Vh_gnn_layers: int = 1
     use_rnn: bool = True              # --no-rnn: networks without a recurrent cell (policy.py:31-32, value.py:38-39)
-    rnn_layers: int = 1               # stacked GRU cells (dgppo/nn/rnn.py:17-29); the DGPPO constraint-value net keeps ONE
+    use_lstm: bool = False            # --use-lstm: flax LSTMCell instead of GRUCell in the policy and Vl (rnn.py:22-24)
+    rnn_layers: int = 1               # stacked cells (dgppo/nn/rnn.py:17-29); the DGPPO constraint-value net keeps ONE
     lagr_init: float = 0.78           # InforMARL-Lagrangian: initial multipliers, their step size (informarl_lagr.py:52-53)
     lr_lagr: float = 1e-7
     cost_weight: float = 0.0          # InforMARL: weight of sum(max(cost, 0)) in the stage cost (informarl.py:329)
@@ -139,7 +140,9 @@ class Engine:
         def rnn_kw(name):
             if not hyper.use_rnn:
                 return dict(rnn="none", rnn_layers=0)
-            return dict(rnn="gru", rnn_layers=1 if (name == "Vh" and algo == "dgppo") else hyper.rnn_layers)
+            if name == "Vh" and algo == "dgppo":        # ValueNet(use_lstm=False) with the default single cell (dgppo.py:83-95)
+                return dict(rnn="gru", rnn_layers=1)
+            return dict(rnn="lstm" if hyper.use_lstm else "gru", rnn_layers=hyper.rnn_layers)
         sizes = [nets.make_layout(kind, cfg.node_dim, layers, n_out, **rnn_kw(k)).size for k, kind, layers, n_out in spec]
         offs, tot = [], 0
         for sz in sizes:

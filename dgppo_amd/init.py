@@ -61,17 +61,29 @@ def _gru(rng):
             "hz": {"kernel": orthogonal(rng, 64, 64)}, "hn": {"kernel": orthogonal(rng, 64, 64), "bias": z()}}
 
 
-def _rnn(rng, rnn_layers: int) -> dict:
-    """RNN_0 of dgppo/nn/rnn.py:14-30: layer l's cell is auto-named GRUCell_{2l+1}"""
+def _lstm(rng):
+    """flax nn.LSTMCell(64): input Denses without bias (lecun-normal), hidden Denses with bias (orthogonal)"""
+    p = {}
+    for g in "ifgo":
+        p["i" + g] = {"kernel": lecun_normal(rng, 64, 64)}
+        p["h" + g] = {"kernel": orthogonal(rng, 64, 64), "bias": np.zeros(64, np.float32)}
+    return p
+
+
+def _rnn(rng, rnn_layers: int, lstm: bool = False) -> dict:
+    """RNN_0 of dgppo/nn/rnn.py:14-30: layer l's cell is auto-named GRUCell_{2l+1} / LSTMCell_{3l+2} (one / two
+    isinstance probes instantiate the class before the instance in use)"""
+    if lstm:
+        return {f"LSTMCell_{3 * l + 2}": _lstm(rng) for l in range(rnn_layers)}
     return {f"GRUCell_{2 * l + 1}": _gru(rng) for l in range(rnn_layers)}
 
 
-def init_policy(seed: int, node_dim: int, action_dim: int, gnn_layers: int, rnn_layers: int = 1) -> dict:
+def init_policy(seed: int, node_dim: int, action_dim: int, gnn_layers: int, rnn_layers: int = 1, lstm: bool = False) -> dict:
     """rnn_layers = 0: --no-rnn (no RNN_0 entry)"""
     rng = np.random.default_rng([seed, 1])
     base = {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "PolicyGNNHead": _mlp(rng)}
     if rnn_layers > 0:
-        base["RNN_0"] = _rnn(rng, rnn_layers)
+        base["RNN_0"] = _rnn(rng, rnn_layers, lstm)
     return {"params": {
         "PolicyNet_0": base,
         "ScaleHid": _dense(rng, 64, 64, scale=0.01),
@@ -80,8 +92,8 @@ def init_policy(seed: int, node_dim: int, action_dim: int, gnn_layers: int, rnn_
 
 
 def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, stream: int, global_info: bool = False,
-               rnn_layers: int = 1) -> dict:
+               rnn_layers: int = 1, lstm: bool = False) -> dict:
     """global_info: DecRStateFn(use_global_info=True) — the head's first Dense takes [x_i | mean_j x_j] (value.py:66-68)"""
     rng = np.random.default_rng([seed, stream])
     return {"params": {"GraphTransformerGNN_0": _gnn(rng, node_dim, gnn_layers), "ValueGNNHead": _mlp(rng, 128 if global_info else 64),
-                       **({"RNN_0": _rnn(rng, rnn_layers)} if rnn_layers > 0 else {}), "Dense_0": _dense(rng, 64, n_out)}}
+                       **({"RNN_0": _rnn(rng, rnn_layers, lstm)} if rnn_layers > 0 else {}), "Dense_0": _dense(rng, 64, n_out)}}

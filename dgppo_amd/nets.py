@@ -60,7 +60,11 @@ def make_layout(kind: str, node_dim: int, gnn_layers: int, n_out: int, rnn: str 
         L.add(f"mlp.be{i}", HID)
     # recurrent stack (dgppo/nn/rnn.py:14-30): layer 0 keeps the historical names, layer l >= 1 is "gru{l}.*"; rnn == "none"
     # (--no-rnn: PolicyNet / ValueNet without a cell, policy.py:31-32, value.py:38-39) has no recurrent parameters
-    assert rnn in ("gru", "none"), rnn
+    assert rnn in ("gru", "lstm", "none"), rnn
+    for l in range(rnn_layers if rnn == "lstm" else 0):   # flax LSTMCell: input Denses without bias, hidden Denses with
+        L.add(f"lstm{l}.Wi", HID, 4 * HID)   # ii | if | ig | io
+        L.add(f"lstm{l}.Wh", HID, 4 * HID)   # hi | hf | hg | ho
+        L.add(f"lstm{l}.bh", 4 * HID)
     for l in range(rnn_layers if rnn == "gru" else 0):
         pre = "gru" if l == 0 else f"gru{l}"
         L.add(f"{pre}.Wi", HID, 3 * HID)   # ir | iz | in
@@ -130,8 +134,10 @@ class Net:
         rnn / rnn_layers: "gru" x L stacked cells (dgppo/nn/rnn.py:14-30; the carry of a row is [L * 64]) or "none"."""
         assert kind in ("policy", "Vl", "Vh", "Vhg")
         self.kind, self.cfg, self.gnn_layers, self.n_out, self.device = kind, cfg, gnn_layers, n_out, device
-        self.rnn, self.rnn_layers = rnn, (rnn_layers if rnn == "gru" else 0)
-        self.carry_dim = HID * max(self.rnn_layers, 1)
+        self.rnn, self.rnn_layers = rnn, (rnn_layers if rnn != "none" else 0)
+        # packed carry of one row: GRU [h_0 | h_1 | ...]; LSTM [c_0 | h_0 | c_1 | h_1 | ...] (the reference stacks (c, h) as
+        # carries 0 and 1 of a layer, rnn.py:23-24); without a cell 64 zeros pass through
+        self.carry_dim = HID * max(self.rnn_layers, 1) * (2 if rnn == "lstm" else 1)
         self.layout = make_layout(kind, cfg.node_dim, gnn_layers, n_out, rnn, rnn_layers)
         self.params = torch.zeros(self.layout.size, device=device)
         if grads is None:
@@ -232,14 +238,14 @@ class Net:
             x = xcat
         act["Rh"], act["n_inner"], act["mlp_in"] = Rh, n_inner, x
         gi = A.get(f"{tag}.gi", Rh, 3 * HID)
-        if self.kind == "Vhg" or self.rnn == "none":
+        if self.kind == "Vhg" or self.rnn != "gru":
             # 128-wide first Dense: the separate Dense / LayerNorm+ReLU kernels (the fused trunk kernel is 64-wide)
             sv = {nm: A.get(f"{tag}.{nm}", Rh, w) for nm, w in (("p1", HID), ("y1", HID), ("st1", 2), ("p2", HID), ("y2", HID), ("st2", 2))}
             K.dense_fwd(x, self.p("mlp.W1"), self.p("mlp.b1"), sv["p1"])
             K.ln_relu_fwd(sv["p1"], self.p("mlp.g1"), self.p("mlp.be1"), sv["y1"], sv["st1"])
             K.dense_fwd(sv["y1"], self.p("mlp.W2"), self.p("mlp.b2"), sv["p2"])
             K.ln_relu_fwd(sv["p2"], self.p("mlp.g2"), self.p("mlp.be2"), sv["y2"], sv["st2"])
-            if self.rnn != "none":
+            if self.rnn == "gru":
                 K.dense_fwd(sv["y2"], self.p("gru.Wi"), self.p("gru.bi"), gi)
             act.update(sv)
         else:
@@ -279,6 +285,32 @@ class Net:
                     hs_out.copy_(h0)
                 else:
                     hs_out.zero_()
+        elif self.rnn == "lstm":
+            # LSTM cells (rnn.py:22-24): per layer an input projection (Dense without bias) and the scan kernel; the carry of
+            # a row packs (c_l, h_l) per layer
+            x_l = act["y2"]
+            act["stack"] = []
+            for l in range(L):
+                zi = A.get(f"{tag}.zi{l}", Rh, 4 * HID)
+                for half in (slice(0, 2 * HID), slice(2 * HID, 4 * HID)):        # the Dense kernels take N <= 192: two 128-wide halves
+                    K.dense_fwd(x_l, self.p(f"lstm{l}.Wi")[:, half], None, zi[:, half])
+                c0_l = h0_l = None
+                if h0 is not None:
+                    c0_l, h0_l = A.get(f"{tag}.c0_{l}", n_seq, HID), A.get(f"{tag}.h0_{l}", n_seq, HID)
+                    c0_l.copy_(h0[:, (2 * l) * HID:(2 * l + 1) * HID])
+                    h0_l.copy_(h0[:, (2 * l + 1) * HID:(2 * l + 2) * HID])
+                cs_l, hs_l = A.get(f"{tag}.cs{l}", Rh, HID), A.get(f"{tag}.hs{l}", Rh, HID)
+                cprev_l = A.get(f"{tag}.cprev{l}", Rh, HID) if train else None
+                hprev_l = A.get(f"{tag}.hprev{l}", Rh, HID) if train else None
+                gates_l = A.get(f"{tag}.gates{l}", Rh, 4 * HID) if train else None
+                K.lstm_fwd(zi, self.p(f"lstm{l}.Wh"), self.p(f"lstm{l}.bh"), c0_l, h0_l, cs_l, hs_l, cprev_l, hprev_l, gates_l,
+                           n_seq, T, n_inner)
+                if hs_out is not None:
+                    hs_out[:, (2 * l) * HID:(2 * l + 1) * HID].copy_(cs_l)
+                    hs_out[:, (2 * l + 1) * HID:(2 * l + 2) * HID].copy_(hs_l)
+                act["stack"].append(dict(x=x_l, hs=hs_l, cprev=cprev_l, hprev=hprev_l, gates=gates_l))
+                x_l = hs_l
+            feat = x_l
         elif not simple:
             # stacked cells (dgppo/nn/rnn.py:17-29): layer l consumes the output sequence of layer l-1; the carry of a row
             # is [h_0 | h_1 | ...].  Separate kernels per layer (input projection, scan); slices of the packed carry are
@@ -342,6 +374,19 @@ class Net:
             K.dense_fwd(dout, self.p("head.Wo"), None, dhs, trans_w=True)
         if self.rnn == "none":
             dy = dhs                                   # the head reads the MLP output directly
+        elif self.rnn == "lstm":
+            stack = act["stack"]
+            for l in range(len(stack) - 1, -1, -1):
+                st = stack[l]
+                dz = A.get(f"{tag}.dz_lstm{l}", Rh, 4 * HID)
+                K.lstm_bwd(dhs, self.p(f"lstm{l}.Wh"), st["cprev"], st["gates"], dz, n_seq, T, n_inner)
+                for half in (slice(0, 2 * HID), slice(2 * HID, 4 * HID)):
+                    K.dense_bwd_w(st["hprev"], dz[:, half], self.g(f"lstm{l}.Wh")[:, half], self.g(f"lstm{l}.bh")[half])
+                    K.dense_bwd_w(st["x"], dz[:, half], self.g(f"lstm{l}.Wi")[:, half], None)
+                dx = A.get(f"{tag}.dy" if l == 0 else f"{tag}.dx{l}", Rh, HID)
+                K.dense_fwd(dz, self.p(f"lstm{l}.Wi"), None, dx, trans_w=True)
+                dhs = dx
+            dy = dhs
         else:
             stack = act.get("stack") or [dict(x=None, gi=act["gi"], hs=act["hs"], hprev=act["hprev"], gates=act["gates"])]
             for l in range(len(stack) - 1, -1, -1):
@@ -440,7 +485,13 @@ class Net:
             self.p(f"mlp.be{i}").copy_(to(hd[f"LayerNorm_{i - 1}"]["bias"]))
         # flax auto-names: each layer of RNN.__call__ instantiates the cell class once for the isinstance
         # probe and once for use (rnn.py:19-20), so layer l's parameters live in GRUCell_{2l+1}
-        for l in range(self.rnn_layers):
+        for l in range(self.rnn_layers if self.rnn == "lstm" else 0):
+            # LSTMCell_{3l+2}: two isinstance probes (GRUCell, LSTMCell) precede the instance in use (rnn.py:19-23)
+            lc = base["RNN_0"][f"LSTMCell_{3 * l + 2}"]
+            self.p(f"lstm{l}.Wi").copy_(torch.cat([to(lc[k]["kernel"]) for k in ("ii", "if", "ig", "io")], dim=1))
+            self.p(f"lstm{l}.Wh").copy_(torch.cat([to(lc[k]["kernel"]) for k in ("hi", "hf", "hg", "ho")], dim=1))
+            self.p(f"lstm{l}.bh").copy_(torch.cat([to(lc[k]["bias"]) for k in ("hi", "hf", "hg", "ho")]))
+        for l in range(self.rnn_layers if self.rnn == "gru" else 0):
             pre = "gru" if l == 0 else f"gru{l}"
             gr = base["RNN_0"][f"GRUCell_{2 * l + 1}"]
             self.p(f"{pre}.Wi").copy_(torch.cat([to(gr[k]["kernel"]) for k in ("ir", "iz", "in")], dim=1))
@@ -475,7 +526,14 @@ class Net:
             head[f"Dense_{i - 1}"] = {"kernel": v(f"mlp.W{i}"), "bias": v(f"mlp.b{i}")}
             head[f"LayerNorm_{i - 1}"] = {"scale": v(f"mlp.g{i}"), "bias": v(f"mlp.be{i}")}
         rnn = {}
-        for l in range(self.rnn_layers):
+        for l in range(self.rnn_layers if self.rnn == "lstm" else 0):
+            Wi, Wh, bh = v(f"lstm{l}.Wi"), v(f"lstm{l}.Wh"), v(f"lstm{l}.bh")
+            cell = {}
+            for q, g_ in enumerate("ifgo"):
+                cell["i" + g_] = {"kernel": Wi[:, q * 64:(q + 1) * 64]}
+                cell["h" + g_] = {"kernel": Wh[:, q * 64:(q + 1) * 64], "bias": bh[q * 64:(q + 1) * 64]}
+            rnn[f"LSTMCell_{3 * l + 2}"] = cell
+        for l in range(self.rnn_layers if self.rnn == "gru" else 0):
             pre = "gru" if l == 0 else f"gru{l}"
             Wi, bi, Wh = v(f"{pre}.Wi"), v(f"{pre}.bi"), v(f"{pre}.Wh")
             rnn[f"GRUCell_{2 * l + 1}"] = {

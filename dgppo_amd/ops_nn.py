@@ -246,3 +246,24 @@ def mean_agents(x, y, G, n, D, backward=False, relu_mask=None):
 def relu_bwd(dy, y):
     rc = N.lib().dgppo_relu_bwd(_p(dy), _p(y), C.c_int64(dy.numel()), N.stream_ptr())
     N.check(rc, "dgppo_relu_bwd")
+
+
+def lstm_fwd(zi, Wh, bh, c0, h0, cs, hs, cprev, hprev, gates, n_seq, T, n_inner):
+    rows = n_seq * T
+    N.expect_shape(zi, (rows, 256), "zi"); N.expect_shape(Wh, (64, 256), "Wh"); N.expect_shape(bh, (256,), "bh")
+    N.expect_shape(cs, (rows, 64), "cs"); N.expect_shape(hs, (rows, 64), "hs")
+    for t, nm in ((c0, "c0"), (h0, "h0")):
+        if t is not None:
+            N.expect_shape(t, (n_seq, 64), nm)
+    FLOPS[0] += 2.0 * rows * 64 * 256
+    rc = N.lib().dgppo_lstm_fwd(_p(zi), _p(Wh), _p(bh), _p(c0), _p(h0), _p(cs), _p(hs), _p(cprev), _p(hprev), _p(gates),
+                                n_seq, T, n_inner, N.stream_ptr())
+    N.check(rc, "dgppo_lstm_fwd")
+
+
+def lstm_bwd(dhs, Wh, cprev, gates, dz, n_seq, T, n_inner):
+    rows = n_seq * T
+    N.expect_shape(dhs, (rows, 64), "dhs"); N.expect_shape(dz, (rows, 256), "dz")
+    FLOPS[0] += 2.0 * rows * 64 * 256
+    rc = N.lib().dgppo_lstm_bwd(_p(dhs), _p(Wh), _p(cprev), _p(gates), _p(dz), n_seq, T, n_inner, N.stream_ptr())
+    N.check(rc, "dgppo_lstm_bwd")

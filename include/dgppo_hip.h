@@ -218,6 +218,18 @@ int32_t dgppo_gru_fwd(const float* gi, const float* Wh, const float* bhn, const 
 int32_t dgppo_gru_bwd(const float* dhs, const float* Wh, const float* hprev, const float* gates, float* dgi,
                       float* dgh, int32_t n_seq, int32_t T, int32_t n_inner, void* stream);
 
+/* LSTM scan (train.py --use-lstm; dgppo/nn/rnn.py:22-24 with flax nn.LSTMCell(64): i,f,o sigmoid, g tanh, c' = f c + i g,
+ * h' = o tanh(c'), carry (c, h)).  zi [rows,256] = x [W_ii|W_if|W_ig|W_io] precomputed (flax's input Denses have no bias);
+ * Wh [64,256], bh [256] (the hidden Denses' biases); row addressing as dgppo_gru_fwd.  c0 / h0 [n_seq,64] or NULL.
+ * cs / hs [rows,64]; cprev, hprev [rows,64] and gates [rows,256] (post-activation) are saved for the backward when non-NULL. */
+int32_t dgppo_lstm_fwd(const float* zi, const float* Wh, const float* bh, const float* c0, const float* h0, float* cs,
+                       float* hs, float* cprev, float* hprev, float* gates, int32_t n_seq, int32_t T, int32_t n_inner,
+                       void* stream);
+/* BPTT of the above from the gradient of every step's output: dz [rows,256] = gradient of the gate pre-activations
+ * (then dW_i = x^T dz, dW_h = hprev^T dz, db_h = colsum dz, dx = dz W_i^T outside).                                     */
+int32_t dgppo_lstm_bwd(const float* dhs, const float* Wh, const float* cprev, const float* gates, float* dz,
+                       int32_t n_seq, int32_t T, int32_t n_inner, void* stream);
+
 /* tanh-Normal head (algo/module/policy.py:62-74,191-212 ; distribution.py:10-46).  ms [rows,4] = mean(2)|std_trans(2).
  * mode 0 sample (eps [rows,2]) -> action, log_pi; 1 mode -> action = tanh(mean); 2 eval (action_in, eps = the constant
  * entropy noise [n_agents,2]) -> log_pi, entropy and, when dms != NULL, the PPO clipped-surrogate loss gradient

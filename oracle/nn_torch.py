@@ -91,16 +91,18 @@ def init_gru(gen, f_in=64, hid=64):
     }
 
 
-def _init_rnn(gen, rnn_layers: int):
+def _init_rnn(gen, rnn_layers: int, lstm: bool = False):
+    if lstm:
+        return {f"LSTMCell_{3 * l + 2}": init_lstm(gen) for l in range(rnn_layers)}
     return {f"GRUCell_{2 * l + 1}": init_gru(gen) for l in range(rnn_layers)}
 
 
-def init_policy(seed: int, node_dim: int, action_dim: int = 2, gnn_layers: int = 2, rnn_layers: int = 1):
+def init_policy(seed: int, node_dim: int, action_dim: int = 2, gnn_layers: int = 2, rnn_layers: int = 1, lstm: bool = False):
     """actor.pkl tree of SURVEY A.9 (dgppo/algo/module/policy.py:20-78,149-180).  rnn_layers = 0: --no-rnn."""
     gen = torch.Generator().manual_seed(seed)
     base = {"GraphTransformerGNN_0": init_gnn(gen, node_dim, gnn_layers), "PolicyGNNHead": init_mlp(gen, 64)}
     if rnn_layers > 0:
-        base["RNN_0"] = _init_rnn(gen, rnn_layers)
+        base["RNN_0"] = _init_rnn(gen, rnn_layers, lstm)
     return {"params": {
         "PolicyNet_0": base,
         "ScaleHid": _dense(gen, 64, 64, scale=0.01),
@@ -109,14 +111,15 @@ def init_policy(seed: int, node_dim: int, action_dim: int = 2, gnn_layers: int =
     }}
 
 
-def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, global_info: bool = False, rnn_layers: int = 1):
+def init_value(seed: int, node_dim: int, n_out: int, gnn_layers: int, global_info: bool = False, rnn_layers: int = 1,
+               lstm: bool = False):
     """Vl.pkl / Vh.pkl trees (dgppo/algo/module/value.py:15-79).  global_info: DecRStateFn(use_global_info=True), whose
     head sees [x_i | mean_j x_j] (value.py:66-68), i.e. a 128-wide first Dense."""
     gen = torch.Generator().manual_seed(seed)
     return {"params": {
         "GraphTransformerGNN_0": init_gnn(gen, node_dim, gnn_layers),
         "ValueGNNHead": init_mlp(gen, 128 if global_info else 64),
-        **({"RNN_0": _init_rnn(gen, rnn_layers)} if rnn_layers > 0 else {}),
+        **({"RNN_0": _init_rnn(gen, rnn_layers, lstm)} if rnn_layers > 0 else {}),
         "Dense_0": _dense(gen, 64, n_out),
     }}
 
@@ -173,6 +176,26 @@ def gru_cell(p, h, x):
     return (1.0 - z) * n + z * h
 
 
+def init_lstm(gen, f_in=64, hid=64):
+    """flax nn.LSTMCell(features=64): input Denses ii/if/ig/io without bias (lecun-normal), hidden Denses hi/hf/hg/ho with
+    bias (orthogonal)  [upstream]"""
+    p = {}
+    for g_ in "ifgo":
+        p["i" + g_] = {"kernel": lecun_normal(gen, f_in, hid)}
+        p["h" + g_] = {"kernel": orthogonal(gen, hid, hid), "bias": torch.zeros(hid)}
+    return p
+
+
+def lstm_cell(p, c, h, x):
+    """flax nn.LSTMCell [upstream]: returns (new_c, new_h)."""
+    i = torch.sigmoid(dense(p["ii"], x) + dense(p["hi"], h))
+    f = torch.sigmoid(dense(p["if"], x) + dense(p["hf"], h))
+    g = torch.tanh(dense(p["ig"], x) + dense(p["hg"], h))
+    o = torch.sigmoid(dense(p["io"], x) + dense(p["ho"], h))
+    new_c = f * c + i * g
+    return new_c, o * torch.tanh(new_c)
+
+
 def rnn_apply(p_rnn, h, x):
     """RNN (dgppo/nn/rnn.py:14-30) with GRU cells.  p_rnn = the params of 'RNN_0' ({'GRUCell_{2l+1}': ...}: every layer
     instantiates the cell class once for the isinstance probe and once for use) or None (--no-rnn: the net
@@ -182,8 +205,12 @@ def rnn_apply(p_rnn, h, x):
     names = sorted(p_rnn.keys(), key=lambda k: int(k.split("_")[1]))
     hs = []
     for l, name in enumerate(names):
-        hl = gru_cell(p_rnn[name], h[..., l * 64:(l + 1) * 64], x)
-        hs.append(hl)
+        if name.startswith("LSTMCell"):   # packed carry [c_l | h_l] per layer (rnn.py:23-24: carries 0 and 1 of the layer)
+            cl, hl = lstm_cell(p_rnn[name], h[..., (2 * l) * 64:(2 * l + 1) * 64], h[..., (2 * l + 1) * 64:(2 * l + 2) * 64], x)
+            hs += [cl, hl]
+        else:
+            hl = gru_cell(p_rnn[name], h[..., l * 64:(l + 1) * 64], x)
+            hs.append(hl)
         x = hl
     return x, torch.cat(hs, dim=-1)
 
@@ -192,7 +219,8 @@ def carry_width(tree) -> int:
     """width of the packed carry of a policy / value tree: 64 per stacked cell (64 of pass-through zeros without a cell)"""
     p = tree["params"]
     p = p.get("PolicyNet_0", p)
-    return 64 * max(len(p.get("RNN_0", {})), 1)
+    cells = p.get("RNN_0", {})
+    return 64 * max(len(cells), 1) * (2 if any(k.startswith("LSTMCell") for k in cells) else 1)
 
 
 def segment_softmax(logits: Tensor, seg: Tensor, num_segments: int) -> Tensor:

@@ -327,10 +327,11 @@ def test_epoch_ppo_runs_that_many_passes(cuda):
         assert float(algo.engine.opt[k].state[2]) == 3 * (16 // 4)
 
 
-@pytest.mark.parametrize("flags,shape", [(dict(use_rnn=False), (1, 3, 1, 64)), (dict(rnn_layers=2), (2, 3, 1, 64))])
+@pytest.mark.parametrize("flags,shape", [(dict(use_rnn=False), (1, 3, 1, 64)), (dict(rnn_layers=2), (2, 3, 1, 64)),
+                                         (dict(use_lstm=True), (1, 3, 2, 64)), (dict(use_lstm=True, rnn_layers=2), (2, 3, 2, 64))])
 def test_rnn_option_flags_through_the_algo_surface(cuda, flags, shape):
-    """--no-rnn / --rnn-layers (train.py:30-33): carries have the reference's (n_layers, n_agents, n_carries, 64) shape at
-    the API, act / collect / update run, and --use-lstm is refused loudly."""
+    """--no-rnn / --rnn-layers / --use-lstm (train.py:30-33): carries have the reference's (n_layers, n_agents, n_carries,
+    64) shape at the API (n_carries = 2 for the LSTM's (c, h)), act / collect / update run."""
     from dgppo.algo import make_algo
     from dgppo.env import make_env
     env = make_env("LidarSpread", 3, num_obs=1, max_step=16)
@@ -350,5 +351,3 @@ def test_rnn_option_flags_through_the_algo_surface(cuda, flags, shape):
     assert ro.rnn_states.shape == (16, 16) + shape
     info = algo.update(ro, 0)
     assert all(np.isfinite(v) for v in info.values())
-    with pytest.raises(NotImplementedError, match="lstm"):
-        make_algo(algo="dgppo", **kw, use_lstm=True)

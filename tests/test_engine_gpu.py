@@ -21,15 +21,17 @@ def _np_rollout(ro):
                 log_pis=c(ro.log_pis), rnn_states=c(ro.rnn_states.contiguous()), rewards=c(ro.rewards), costs=c(ro.costs))
 
 
-def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step, use_rnn=True, rnn_layers=1, **engine_kw):
+def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step, use_rnn=True, rnn_layers=1, use_lstm=False, **engine_kw):
     from dgppo_amd import _native as N, engine as EN, init
     kind = N.ENV_KINDS[kind_name]
     cfg = N.make_env_cfg(kind, n, n_obs)
     ocfg = E.EnvCfg(kind, n_agents=n, n_obs=n_obs)
-    hp = EN.Hyper(batch_size=batch_size, rnn_step=rnn_step, train_steps=100, use_rnn=use_rnn, rnn_layers=rnn_layers)
+    hp = EN.Hyper(batch_size=batch_size, rnn_step=rnn_step, train_steps=100, use_rnn=use_rnn, rnn_layers=rnn_layers,
+                  use_lstm=use_lstm)
     eng = EN.Engine(cfg, hp, cuda, T=T_, **engine_kw)
     nc = rnn_layers if use_rnn else 0
-    trees = {"policy": init.init_policy(0, cfg.node_dim, 2, 2, nc), "Vl": init.init_value(0, cfg.node_dim, 1, 2, 2, rnn_layers=nc),
+    trees = {"policy": init.init_policy(0, cfg.node_dim, 2, 2, nc, use_lstm),
+             "Vl": init.init_value(0, cfg.node_dim, 1, 2, 2, rnn_layers=nc, lstm=use_lstm),
              "Vh": init.init_value(0, cfg.node_dim, 2, 1, 3, rnn_layers=min(nc, 1))}
     rng = np.random.default_rng(11)
     jitter = lambda tr: T.tree_map(lambda a: torch.from_numpy(a + 0.05 * rng.standard_normal(a.shape).astype(np.float32)), tr)
@@ -513,14 +515,14 @@ def test_informarl_lagr_targets_gradients_and_multipliers(cuda):
     assert abs(info["policy/lagr_mean"] - float(want.mean())) < 1e-5
 
 
-@pytest.mark.parametrize("use_rnn,rnn_layers", [(False, 1), (True, 2)])
-def test_rnn_options_targets_and_gradients(cuda, use_rnn, rnn_layers):
-    """train.py --no-rnn and --rnn-layers 2 through the whole engine (rollout with the packed carry, value pre-passes where
+@pytest.mark.parametrize("use_rnn,rnn_layers,use_lstm", [(False, 1, False), (True, 2, False), (True, 1, True), (True, 2, True)])
+def test_rnn_options_targets_and_gradients(cuda, use_rnn, rnn_layers, use_lstm):
+    """train.py --no-rnn, --rnn-layers 2 and --use-lstm through the whole engine (rollout with the packed carry, value pre-passes where
     the one-cell constraint-value net reads layer 0 of the actor's carry, GAE, first-minibatch gradients) vs the oracle."""
     kind, n, n_obs, B, T_, rs, bs = "LidarSpread", 3, 2, 4, 8, 4, 16
     cfg, ocfg, hp, eng, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs, use_rnn=use_rnn, rnn_layers=rnn_layers,
-                                       multi_stream=True)
-    assert eng.HC == 64 * (rnn_layers if use_rnn else 1)
+                                       use_lstm=use_lstm, multi_stream=True)
+    assert eng.HC == 64 * (rnn_layers if use_rnn else 1) * (2 if use_lstm else 1)
     seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
     ro = eng.rollout(seeds, True, noise_seed=3)
     det = eng.rollout(seeds + 1000, False)
@@ -538,7 +540,7 @@ def test_rnn_options_targets_and_gradients(cuda, use_rnn, rnn_layers):
     wt = R.targets(leaf, ocfg, r, d, hpd, w)
     for k in ("Vl", "Vh", "Vh_det", "Ql", "Qh", "Qh_det"):
         _close(tg[k], wt[k], k)
-    _check_advantage(tg, wt, ocfg.dt, hp.alpha, hp.cbf_eps, w, f"rnn={use_rnn} x{rnn_layers}")
+    _check_advantage(tg, wt, ocfg.dt, hp.alpha, hp.cbf_eps, w, f"rnn={use_rnn} x{rnn_layers} lstm={use_lstm}")
     perm = np.array([2, 0, 3, 1])
     grads = {}
 

@@ -678,21 +678,21 @@ def test_Vh_global_info_forward_backward(cuda, kind, n, n_obs):
     _grad_tree_close(net, lt, 3e-5)
 
 
-@pytest.mark.parametrize("rnn_layers", [0, 2, 3])
-def test_policy_and_Vl_with_rnn_options(cuda, rnn_layers):
+@pytest.mark.parametrize("rnn_layers,lstm", [(0, False), (2, False), (3, False), (1, True), (2, True)])
+def test_policy_and_Vl_with_rnn_options(cuda, rnn_layers, lstm):
     """--no-rnn (rnn_layers = 0 here: no cell, the MLP output feeds the head, the carry passes through: policy.py:29-33)
-    and stacked GRU cells (--rnn-layers L: layer l consumes layer l-1's output, packed carry [h_0 | h_1 | ...],
-    dgppo/nn/rnn.py:17-29): chunk scan with a NON-zero initial carry, forward and backward against the oracle."""
+    stacked GRU cells (--rnn-layers L: layer l consumes layer l-1's output, packed carry [h_0 | h_1 | ...],
+    dgppo/nn/rnn.py:17-29) and LSTM cells (--use-lstm, packed carry [c_0 | h_0 | ...], rnn.py:22-24): chunk scan with a NON-zero initial carry, forward and backward against the oracle."""
     from dgppo_amd import nets, ops_nn as K_
     kind, n, n_obs, n_env, T_ = E.LIDAR_SPREAD, 3, 2, 3, 5
     cfg, ocfg, ag, goal, obst, hi, gr = _scene(kind, n, n_obs, n_env, T_, seed=17)
     gen = torch.Generator().manual_seed(5 + rnn_layers)
     jit = lambda tr: T.tree_map(lambda t: t + 0.05 * torch.randn(t.shape, generator=gen), tr)
-    ptree = jit(T.init_policy(1, cfg.node_dim, rnn_layers=rnn_layers))
+    ptree = jit(T.init_policy(1, cfg.node_dim, rnn_layers=rnn_layers, lstm=lstm))
     ptree["params"]["ScaleHid"]["kernel"] = T.orthogonal(gen, 64, 64, 0.5)
-    vtree = jit(T.init_value(2, cfg.node_dim, 1, 2, rnn_layers=rnn_layers))
-    kw = dict(rnn="gru", rnn_layers=rnn_layers) if rnn_layers > 0 else dict(rnn="none", rnn_layers=0)
-    CD = 64 * max(rnn_layers, 1)
+    vtree = jit(T.init_value(2, cfg.node_dim, 1, 2, rnn_layers=rnn_layers, lstm=lstm))
+    kw = dict(rnn="lstm" if lstm else "gru", rnn_layers=rnn_layers) if rnn_layers > 0 else dict(rnn="none", rnn_layers=0)
+    CD = 64 * max(rnn_layers, 1) * (2 if lstm else 1)
     feats = _feats(cfg, ag, goal, obst, hi, cuda)
     g_t = T.graph_to_torch(gr)
     gsel = lambda t: {k: v.view((n_env, T_) + v.shape[1:])[:, t] for k, v in g_t.items()}

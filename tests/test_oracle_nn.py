@@ -370,3 +370,30 @@ def test_autograd_twin_matches_finite_differences():
             return T.value_Vh(tree, g, h, 2)[0]
         w = base.clone().requires_grad_()
         assert torch.autograd.gradcheck(f, (w,), eps=1e-6, atol=1e-5, rtol=1e-4, nondet_tol=1e-9), name
+
+
+def test_lstm_cell_matches_torch_lstmcell():
+    """oracle lstm_cell (flax nn.LSTMCell restated: input Denses without bias, hidden Denses with bias, gates i f g o,
+    c' = f c + i g, h' = o tanh(c')) vs torch.nn.LSTMCell with the same gate order."""
+    g = _gen(12)
+    p = T.init_lstm(g, 64, 64)
+    for k in ("hi", "hf", "hg", "ho"):
+        p[k]["bias"] = 0.3 * torch.randn(64, generator=g)
+    cell = torch.nn.LSTMCell(64, 64)
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.cat([p["i" + q]["kernel"].T for q in "ifgo"], 0))
+        cell.weight_hh.copy_(torch.cat([p["h" + q]["kernel"].T for q in "ifgo"], 0))
+        cell.bias_ih.zero_()
+        cell.bias_hh.copy_(torch.cat([p["h" + q]["bias"] for q in "ifgo"]))
+    x, h, c = (torch.randn(11, 64, generator=g) for _ in range(3))
+    h_w, c_w = cell(x, (h, c))
+    c_g, h_g = T.lstm_cell(p, c, h, x)
+    assert torch.allclose(h_g, h_w, atol=1e-6) and torch.allclose(c_g, c_w, atol=1e-6)
+    # stacked application through rnn_apply: packed carry [c_0 | h_0 | c_1 | h_1]
+    prnn = {"LSTMCell_2": p, "LSTMCell_5": T.init_lstm(g, 64, 64)}
+    carry = torch.randn(11, 256, generator=g)
+    out, new = T.rnn_apply(prnn, carry, x)
+    c0, h0 = T.lstm_cell(prnn["LSTMCell_2"], carry[:, :64], carry[:, 64:128], x)
+    c1, h1 = T.lstm_cell(prnn["LSTMCell_5"], carry[:, 128:192], carry[:, 192:], h0)
+    assert torch.equal(out, h1) and torch.equal(new, torch.cat([c0, h0, c1, h1], -1))
+    assert T.carry_width({"params": {"RNN_0": prnn}}) == 256
