@@ -158,6 +158,15 @@ int32_t dgppo_dense_fwd(const float* X, int32_t ldx, const float* W, int32_t ldw
 int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
                           float* db, int32_t M, int32_t K, int32_t N, float* workspace, int64_t workspace_bytes,
                           void* stream);
+/* The MLP trunk and the GRU input projection as PPOPolicy / ValueNet compose them (dgppo/algo/module/policy.py:191-212,
+ * value.py:58-80) in one launch: y1 = relu(LN(X W1 + b1)), y2 = relu(LN(y1 W2 + b2)) (MLP of dgppo/nn/mlp.py:17-29, hidden
+ * 64, LayerNorm scale g / bias be, eps 1e-6), gi = y2 Wi + bi [M,192] (the input half of flax GRUCell, dgppo/nn/rnn.py:14-30,
+ * gates r|z|n).  X [M, >= 64] with leading dimension ldx.  p1/y1/st1/p2/y2/st2 (pre-LN [M,64], post-ReLU [M,64], LN
+ * statistics [M,2] per layer) are what the backward needs: all six or none (inference).                          */
+int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1, const float* b1, const float* g1, const float* be1,
+                         const float* W2, const float* b2, const float* g2, const float* be2, const float* Wi,
+                         const float* bi, float* p1, float* y1, float* st1, float* p2, float* y2, float* st2, float* gi,
+                         int32_t M, void* stream);
 /* One GRU step (T = 1) fused with the output Dense layer(s) on the same rows — the tail of a rollout step:
  * h' = GRUCell(gi, h0) (dgppo/nn/rnn.py:14-30, gi = x W_i + b_i from dgppo_mlp_gi_fwd), then either the policy head
  * u = h' W1 + b1 [64], out = u W2 + b2 (PolicyNet.head Dense -> TanhNormal Dense, dgppo/algo/module/policy.py:62-74; pass

@@ -28,6 +28,12 @@ def test_library_loads_and_exports_all_declared_symbols():
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, f"declared in include/ but not exported: {missing}"
     assert lib.dgppo_abi_version() == N.ABI_VERSION
+    # and the other direction: nothing is exported that the header does not declare (debug hooks of -DDGPPO_STAMPS builds aside)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T dgppo_" in ln}
+    undeclared = sorted(s for s in exported - set(syms) if not s.startswith("dgppo_debug_"))
+    assert not undeclared, f"exported but not declared in include/: {undeclared}"
 
 
 def test_cfg_struct_matches_header_and_sizes():
