@@ -284,6 +284,74 @@ static void launch_dense(const DenseArgs& a, hipStream_t s) {
   else launch_dense_kq<NTW, RTW, CG, 16>(a, s);
 }
 
+// ---- narrow inputs (K <= 16): the query projection of the first GNN layer (K = 8), the input gradients of the 4- /
+// 1- / 2-wide heads.  These move 100+ bytes per row for a handful of FMAs: a tile pipeline with a barrier per 32 rows
+// (above) runs at its latency floor (23 us for 17 MB).  Here a thread owns four consecutive output columns of a row, the
+// whole W (<= 16 x 192) sits in LDS in [k][n] order (transposed on the way in if trans_w), X is read straight from global
+// memory (the threads of a row read the same addresses: one L1 broadcast) and Y is written as coalesced 16-byte stores.
+#define DSK_MAXK 16
+template <bool VECY>
+__global__ void __launch_bounds__(256) dense_smallk_kernel(DenseArgs a) {
+  __shared__ float sW[DSK_MAXK * 192 + 192];
+  const int K = a.K, N = a.N, nq = (N + 3) >> 2, Nl = nq * 4;
+  for (int idx = threadIdx.x; idx < K * Nl; idx += 256) {
+    const int k = idx / Nl, c = idx - k * Nl;
+    float w = 0.0f;
+    if (c < N) w = a.trans_w ? a.W[(size_t)c * a.ldw + k] : a.W[(size_t)k * a.ldw + c];
+    sW[idx] = w;
+  }
+  for (int c = threadIdx.x; c < Nl; c += 256) sW[K * Nl + c] = (a.bias && c < N) ? a.bias[c] : 0.0f;
+  __syncthreads();
+  const long items = (long)a.M * nq;
+  const uint32_t rcp = (uint32_t)((0x100000000ull + nq - 1) / nq);    // item / nq as a multiply-high (exact below 2^32 / nq items)
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < items; it += (long)gridDim.x * 256) {
+    const int row = (int)__umulhi((uint32_t)it, rcp);
+    const int c0 = ((int)it - row * nq) * 4;
+    const float* x = a.X + (size_t)row * a.ldx;
+    float4 acc = *reinterpret_cast<const float4*>(sW + K * Nl + c0);
+    for (int k = 0; k < K; ++k) {
+      const float xv = x[k];
+      const float4 w = *reinterpret_cast<const float4*>(sW + k * Nl + c0);
+      acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y); acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+    }
+    float* y = a.Y + (size_t)row * a.ldy + c0;
+    float r[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (VECY) {
+      if (a.accumulate) { const float4 o = *reinterpret_cast<const float4*>(y); r[0] += o.x; r[1] += o.y; r[2] += o.z; r[3] += o.w; }
+      if (a.act == 1) { r[0] = fmaxf(r[0], 0.f); r[1] = fmaxf(r[1], 0.f); r[2] = fmaxf(r[2], 0.f); r[3] = fmaxf(r[3], 0.f); }
+      if (a.mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(a.mask + (size_t)row * a.ldm + c0);
+        r[0] = mk.x > 0.f ? r[0] : 0.f; r[1] = mk.y > 0.f ? r[1] : 0.f; r[2] = mk.z > 0.f ? r[2] : 0.f; r[3] = mk.w > 0.f ? r[3] : 0.f;
+      }
+      *reinterpret_cast<float4*>(y) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+      for (int u = 0; u < 4; ++u) {
+        if (c0 + u >= N) break;
+        float v = r[u];
+        if (a.accumulate) v += y[u];
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        if (a.mask) v = a.mask[(size_t)row * a.ldm + c0 + u] > 0.f ? v : 0.f;
+        y[u] = v;
+      }
+    }
+  }
+}
+
+static bool dense_smallk_ok(const DenseArgs& a) {
+  const long nq = (a.N + 3) / 4;                    // the multiply-high row index is exact while items * nq < 2^32
+  return a.K <= DSK_MAXK && a.N <= 192 && (long)a.M * nq * nq < (1l << 32) && !getenv("DGPPO_DENSE_NO_SMALLK") &&
+         !getenv("DGPPO_DENSE_NO_SMALLK_FWD");
+}
+static void launch_dense_smallk(const DenseArgs& a, hipStream_t s) {
+  const long items = (long)a.M * ((a.N + 3) / 4);
+  long blocks = (items + 256 * 4 - 1) / (256 * 4);            // >= 4 items per thread amortise the staging of W
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  const bool vec = (a.N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+                   (!a.mask || ((a.ldm & 3) == 0 && (reinterpret_cast<uintptr_t>(a.mask) & 15) == 0));
+  if (vec) hipLaunchKernelGGL(dense_smallk_kernel<true>, dim3((int)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(dense_smallk_kernel<false>, dim3((int)blocks), dim3(256), 0, s, a);
+}
+
 int32_t dense_fwd_launch(const DenseArgs& a, hipStream_t s) {
   DGPPO_REQUIRE(a.M >= 0 && a.K >= 1 && a.N >= 1, "dense: bad shape M=%d K=%d N=%d", a.M, a.K, a.N);
   DGPPO_REQUIRE(a.N <= 192 && a.K <= 256, "dense: N <= 192 and K <= 256 supported (N=%d K=%d)", a.N, a.K);
@@ -291,7 +359,8 @@ int32_t dense_fwd_launch(const DenseArgs& a, hipStream_t s) {
   DGPPO_REQUIRE(a.ldx >= a.K && a.ldy >= a.N, "dense: leading dimensions too small");
   if (a.M == 0) return 0;
   const int nt = cdiv(a.N, 16);
-  if (nt >= 9) launch_dense<3, 2, 4>(a, s);        // N in (128, 192]
+  if (dense_smallk_ok(a)) launch_dense_smallk(a, s);
+  else if (nt >= 9) launch_dense<3, 2, 4>(a, s);   // N in (128, 192]
   else if (nt >= 5) launch_dense<2, 2, 4>(a, s);   // N in (64, 128]
   else if (nt == 4) launch_dense<1, 2, 4>(a, s);   // N in (48, 64]
   else if (nt == 3) launch_dense<2, 1, 2>(a, s);   // N in (32, 48]
@@ -587,6 +656,123 @@ static void launch_bwd_w(const DenseBwdWArgs& a, hipStream_t s) {
   else launch_bwd_w_kt<NT, 16>(a, s);
 }
 
+// ---- narrow weight gradients (K <= 16, N <= 64: dMcat of the first GNN layer, K = 8, N = 24) ------------------------
+// A thread owns four output columns and all K rows of dW (4K accumulators) and walks its share of the M input rows: dY is
+// read as coalesced 16-byte loads, X[m][0..K) is the same address for the N/4 threads of a row.  The row-lanes of a
+// workgroup meet in LDS (float atomics, once per workgroup), the workgroup writes one partial slab, and the common
+// second stage (dense_bwd_w_reduce_kernel) folds the slabs into dW / db.
+template <int KMAX, bool VECX>
+__global__ void __launch_bounds__(256) dense_bwd_w_smallk_kernel(DenseBwdWArgs a) {
+  extern __shared__ float sP[];                     // [256][K*4 + 4 + 1]: every thread's accumulators, then summed per column
+  const int K = a.K, N = a.N, nq = N >> 2;
+  const int per = K * 4 + 4, Pl = per + 1;
+  const int lanes = 256 / nq;                       // row-lanes of the workgroup
+  const int rl = threadIdx.x / nq, cq = threadIdx.x - rl * nq;
+  float4 acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < lanes) {
+    const int r0 = blockIdx.x * a.rows_per_block;
+    const int r1 = min(a.M, r0 + a.rows_per_block);
+    // UR rows in flight per thread: the loop is a chain of dependent loads otherwise (one row = 1 + K/4 requests)
+    constexpr int UR = 4;
+    for (int rb = r0 + rl; rb < r1; rb += lanes * UR) {
+      float4 d[UR];
+      float xv[UR][KMAX];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int r = rb + u * lanes;
+        const bool in = r < r1;
+        const int rr = in ? r : r0;
+        d[u] = *reinterpret_cast<const float4*>(a.dY + (size_t)rr * a.ldy + cq * 4);
+        if (!in) d[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* x = a.X + (size_t)rr * a.ldx;
+        if (VECX) {
+#pragma unroll
+          for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+            if (k4 * 4 < K) {
+              const float4 t = *reinterpret_cast<const float4*>(x + k4 * 4);
+              xv[u][k4 * 4] = t.x; xv[u][k4 * 4 + 1] = t.y; xv[u][k4 * 4 + 2] = t.z; xv[u][k4 * 4 + 3] = t.w;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) if (k < K) xv[u][k] = x[k];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        accb.x += d[u].x; accb.y += d[u].y; accb.z += d[u].z; accb.w += d[u].w;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < K) {
+            acc[k].x = fmaf(xv[u][k], d[u].x, acc[k].x); acc[k].y = fmaf(xv[u][k], d[u].y, acc[k].y);
+            acc[k].z = fmaf(xv[u][k], d[u].z, acc[k].z); acc[k].w = fmaf(xv[u][k], d[u].w, acc[k].w);
+          }
+        }
+      }
+    }
+  }
+  float* mine = sP + threadIdx.x * Pl;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if (k < K) { mine[k * 4] = acc[k].x; mine[k * 4 + 1] = acc[k].y; mine[k * 4 + 2] = acc[k].z; mine[k * 4 + 3] = acc[k].w; }
+  }
+  mine[K * 4] = accb.x; mine[K * 4 + 1] = accb.y; mine[K * 4 + 2] = accb.z; mine[K * 4 + 3] = accb.w;
+  __syncthreads();
+  // output element e = k*N + c (k == K: the bias row) is the sum over the row-lanes of thread (rl, cq = c/4), slot k*4 + c%4
+  float* out = a.part + (size_t)blockIdx.x * a.part_stride;
+  const int E = K * N + N;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const int k = e / N, c = e - k * N;
+    const float* src = sP + (c >> 2) * Pl + k * 4 + (c & 3);
+    float s0 = 0.f, s1 = 0.f;
+    int l = 0;
+    for (; l + 1 < lanes; l += 2) { s0 += src[(size_t)l * nq * Pl]; s1 += src[(size_t)(l + 1) * nq * Pl]; }
+    if (l < lanes) s0 += src[(size_t)l * nq * Pl];
+    out[e] = s0 + s1;
+  }
+}
+
+static bool launch_bwd_w_smallk(DenseBwdWArgs a, hipStream_t s) {
+  if (a.K > 16 || a.N > 64 || (a.N & 3) || (a.ldy & 3) || (reinterpret_cast<uintptr_t>(a.dY) & 15) || a.M < 4096 ||
+      getenv("DGPPO_DENSE_NO_SMALLK") || getenv("DGPPO_DENSE_NO_SMALLK_BWD"))
+    return false;
+  const int stride = ((a.K * a.N + a.N + 63) / 64) * 64;
+  const long max_slabs = a.part ? (long)(a.ws_bytes / (sizeof(float) * stride)) : 0;
+  if (max_slabs < 8) return false;
+  int grid = a.M >= (1 << 19) ? 1024 : 512;          // 2-4 workgroups per CU
+  if (grid > max_slabs) grid = (int)max_slabs;
+  int rpb = cdiv(a.M, grid);
+  grid = cdiv(a.M, rpb);
+  a.rows_per_block = rpb;
+  a.part_stride = stride;
+  const size_t smem = sizeof(float) * 256 * (a.K * 4 + 5);            // <= 69 KB
+  const bool vx = (a.K & 3) == 0 && (a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+  if (a.K <= 8) {
+    if (vx) hipLaunchKernelGGL((dense_bwd_w_smallk_kernel<8, true>), dim3(grid), dim3(256), smem, s, a);
+    else hipLaunchKernelGGL((dense_bwd_w_smallk_kernel<8, false>), dim3(grid), dim3(256), smem, s, a);
+  } else {
+    static thread_local bool opted = false;
+    if (!opted) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bwd_w_smallk_kernel<16, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 69 * 4);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bwd_w_smallk_kernel<16, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 69 * 4);
+      opted = true;
+    }
+    if (vx) hipLaunchKernelGGL((dense_bwd_w_smallk_kernel<16, true>), dim3(grid), dim3(256), smem, s, a);
+    else hipLaunchKernelGGL((dense_bwd_w_smallk_kernel<16, false>), dim3(grid), dim3(256), smem, s, a);
+  }
+  const int E = a.K * a.N + (a.db ? a.N : 0);
+  int splits = cdiv(grid, 32);
+  splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+  hipLaunchKernelGGL(dense_bwd_w_reduce_kernel, dim3(cdiv(E, 256), splits), dim3(256), 0, s, a.part, stride, grid, a.dW,
+                     a.ldw, a.db, a.K, a.N);
+  return true;
+}
+
 int32_t dense_bwd_w_launch(DenseBwdWArgs a, hipStream_t s) {
   DGPPO_REQUIRE(a.M >= 0 && a.K >= 1 && a.N >= 1, "dense_bwd_w: bad shape");
   DGPPO_REQUIRE(a.N <= 192 && a.K <= 256, "dense_bwd_w: N <= 192 and K <= 256 supported (N=%d K=%d)", a.N, a.K);
@@ -594,7 +780,8 @@ int32_t dense_bwd_w_launch(DenseBwdWArgs a, hipStream_t s) {
   DGPPO_REQUIRE(a.ldx >= a.K && a.ldy >= a.N && a.ldw >= a.N, "dense_bwd_w: leading dimensions too small");
   if (a.M == 0) return 0;
   const int nt = cdiv(a.N, 16);
-  if (nt <= 1) launch_bwd_w<1>(a, s);
+  if (launch_bwd_w_smallk(a, s)) {}
+  else if (nt <= 1) launch_bwd_w<1>(a, s);
   else if (nt <= 2) launch_bwd_w<2>(a, s);
   else if (nt <= 4) launch_bwd_w<4>(a, s);
   else if (nt <= 6) launch_bwd_w<6>(a, s);

@@ -635,6 +635,228 @@ __device__ inline float grp8_max(float v) {
   return v;
 }
 
+// ---- narrow layers (F = 8: the first GNN layer, node features padded 7 -> 8): slot-sparse VALU kernels ---------------
+// With 8 features a dense [n*H x nodes] logit tile on the matrix cores computes 3.3x more products than the S slots of
+// an agent need (24 of 80 nodes for LidarSpread n = 8) and needs three dependent memory round trips per graph (operands
+// -> logits through LDS -> P -> aggregation).  Here one wave owns a graph and a group of 8 lanes owns an AGENT: every
+// lane loads the sender rows / edge features / masks of its SJ slots STRAIGHT from global memory, once for all heads
+// (sender ids are static, so every address is known at entry: ONE memory round trip per graph), forms its H * SJ logits
+// with 8 FMAs each, and the per-(agent, head) reductions are DPP row operations.  No LDS, no matrix cores, ~1/3 of the
+// instructions and of the L1 requests; sums run over slots in a different order than the dense form (tests: 1e-5).
+// NPA = ceil(n / 8) passes over groups of 8 agents.
+template <int H, int NPA, int SJ>
+__global__ void __launch_bounds__(256) attn_fwd_slot8_kernel(AttnArgs a) {
+  constexpr int F = 8, Wd = F + 4;
+  const Topo& t = a.t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, grp = lane >> 3;
+  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (g >= a.G) return;
+  const int n = t.n, S = t.S, Ns = t.Ns, Kp = a.Kp, kc = F + H * Wd;
+  const float* Xa = a.Xa + (size_t)g * n * F;
+  const float* Xo = a.Xo + (size_t)g * (Ns - n) * F - (size_t)n * F;   // indexed by node id (>= n)
+  const float* qt = a.qt + (size_t)g * n * H * F;
+  const float* ef = a.efeat + (size_t)g * n * S * 4;
+  const float* mk = a.emask + (size_t)g * n * S;
+  float* zc = a.zcat + (size_t)g * n * Kp;
+  float* at = a.attn + (size_t)g * n * S * H;
+  // the parts of zcat that are plain copies: x_i, the constant column, zero padding
+  for (int idx = lane; idx < n * 2; idx += 64)
+    *reinterpret_cast<float4*>(zc + (idx >> 1) * Kp + 4 * (idx & 1)) = reinterpret_cast<const float4*>(Xa)[idx];
+  for (int i = lane; i < n; i += 64)
+    for (int c = kc; c < Kp; ++c) zc[i * Kp + c] = (c == kc) ? 1.0f : 0.0f;
+#pragma unroll
+  for (int p = 0; p < NPA; ++p) {
+    const int ia = grp + 8 * p;
+    const bool live = ia < n;
+    const int i = live ? ia : n - 1;
+    float4 q[H][2], x[SJ][2], e[SJ];
+    float m[SJ];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float4* qp = reinterpret_cast<const float4*>(qt + (i * H + h) * F);
+      q[h][0] = qp[0]; q[h][1] = qp[1];
+    }
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) {
+      int sl = sub + 8 * j;
+      sl = sl < S ? sl : S - 1;
+      const int nd = sender_node(t, i, sl);
+      const float4* xp = reinterpret_cast<const float4*>((nd < n ? Xa : Xo) + (size_t)nd * F);
+      x[j][0] = xp[0]; x[j][1] = xp[1];
+      e[j] = reinterpret_cast<const float4*>(ef)[i * S + sl];
+      m[j] = mk[i * S + sl];
+    }
+    float av[SJ][H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const bool ok = live && (sub + 8 * j) < S && m[j] != 0.0f;
+        float acc = q[h][0].x * x[j][0].x;
+        acc = fmaf(q[h][0].y, x[j][0].y, acc); acc = fmaf(q[h][0].z, x[j][0].z, acc); acc = fmaf(q[h][0].w, x[j][0].w, acc);
+        acc = fmaf(q[h][1].x, x[j][1].x, acc); acc = fmaf(q[h][1].y, x[j][1].y, acc);
+        acc = fmaf(q[h][1].z, x[j][1].z, acc); acc = fmaf(q[h][1].w, x[j][1].w, acc);
+        av[j][h] = ok ? acc : -INFINITY;
+        mx = fmaxf(mx, av[j][h]);
+      }
+      mx = grp8_max(mx);
+      float den = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const float ev = (av[j][h] == -INFINITY) ? 0.0f : __expf(av[j][h] - mx);   /* v_exp_f32: rel. error ~1e-7 on weights <= 1 */
+        av[j][h] = ev;
+        den += ev;
+      }
+      den = grp8_sum(den);
+      const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) av[j][h] *= inv;
+    }
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) {
+      const int sl = sub + 8 * j;
+      if (live && sl < S) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) at[(i * S + sl) * H + h] = av[j][h];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float z[Wd];
+#pragma unroll
+      for (int c = 0; c < Wd; ++c) z[c] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        const float w = av[j][h];
+        if (w != 0.0f) {   // masked slots (and dead lanes) have w == 0; they may carry 5e5 / NaN features: skip, never multiply
+          z[0] = fmaf(w, x[j][0].x, z[0]); z[1] = fmaf(w, x[j][0].y, z[1]); z[2] = fmaf(w, x[j][0].z, z[2]); z[3] = fmaf(w, x[j][0].w, z[3]);
+          z[4] = fmaf(w, x[j][1].x, z[4]); z[5] = fmaf(w, x[j][1].y, z[5]); z[6] = fmaf(w, x[j][1].z, z[6]); z[7] = fmaf(w, x[j][1].w, z[7]);
+          z[8] = fmaf(w, e[j].x, z[8]); z[9] = fmaf(w, e[j].y, z[9]); z[10] = fmaf(w, e[j].z, z[10]); z[11] = fmaf(w, e[j].w, z[11]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < Wd; ++c) z[c] = grp8_sum(z[c]);
+      if (live && sub == h) {             // lane h of the group stores head h: the stores of the H heads go out together
+        float4* o = reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd);   // (F + h*Wd) % 4 == 0 and Kp % 4 == 0
+        o[0] = make_float4(z[0], z[1], z[2], z[3]);
+        o[1] = make_float4(z[4], z[5], z[6], z[7]);
+        o[2] = make_float4(z[8], z[9], z[10], z[11]);
+      }
+    }
+  }
+}
+
+// backward of the above for the first layer, whose inputs are raw features (no dXa / dXo): dqt only.
+//   dA = dzx . x_s + dze . e  at the slots with a != 0;  dl = a (dA - sum_s a dA);  dqt[i,h,:] = sum_s dl x_s
+template <int H, int NPA, int SJ>
+__global__ void __launch_bounds__(256) attn_bwd_slot8_kernel(AttnArgs a) {
+  constexpr int F = 8, Wd = F + 4;
+  const Topo& t = a.t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 7, grp = lane >> 3;
+  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (g >= a.G) return;
+  const int n = t.n, S = t.S, Ns = t.Ns, Kp = a.Kp;
+  const float* Xa = a.Xa + (size_t)g * n * F;
+  const float* Xo = a.Xo + (size_t)g * (Ns - n) * F - (size_t)n * F;
+  const float* ef = a.efeat + (size_t)g * n * S * 4;
+  const float* at = a.attn + (size_t)g * n * S * H;
+  const float* dzc = a.dzcat + (size_t)g * n * Kp;
+  float* dq = a.dqt + (size_t)g * n * H * F;
+#pragma unroll
+  for (int p = 0; p < NPA; ++p) {
+    const int ia = grp + 8 * p;
+    const bool live = ia < n;
+    const int i = live ? ia : n - 1;
+    float4 dz[H][3], x[SJ][2], e[SJ];
+    float av[SJ][H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float4* zp = reinterpret_cast<const float4*>(dzc + i * Kp + F + h * Wd);
+      dz[h][0] = zp[0]; dz[h][1] = zp[1]; dz[h][2] = zp[2];
+    }
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) {
+      int sl = sub + 8 * j;
+      const bool in = live && sl < S;
+      sl = sl < S ? sl : S - 1;
+      const int nd = sender_node(t, i, sl);
+      const float4* xp = reinterpret_cast<const float4*>((nd < n ? Xa : Xo) + (size_t)nd * F);
+      x[j][0] = xp[0]; x[j][1] = xp[1];
+      e[j] = reinterpret_cast<const float4*>(ef)[i * S + sl];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float w = at[(i * S + sl) * H + h];
+        av[j][h] = in ? w : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float dA[SJ];
+      float dot = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        float acc = 0.0f;
+        if (av[j][h] != 0.0f) {               // masked slots may carry 5e5 / NaN features: skip, never multiply
+          acc = dz[h][0].x * x[j][0].x;
+          acc = fmaf(dz[h][0].y, x[j][0].y, acc); acc = fmaf(dz[h][0].z, x[j][0].z, acc); acc = fmaf(dz[h][0].w, x[j][0].w, acc);
+          acc = fmaf(dz[h][1].x, x[j][1].x, acc); acc = fmaf(dz[h][1].y, x[j][1].y, acc);
+          acc = fmaf(dz[h][1].z, x[j][1].z, acc); acc = fmaf(dz[h][1].w, x[j][1].w, acc);
+          acc = fmaf(dz[h][2].x, e[j].x, acc); acc = fmaf(dz[h][2].y, e[j].y, acc);
+          acc = fmaf(dz[h][2].z, e[j].z, acc); acc = fmaf(dz[h][2].w, e[j].w, acc);
+          dot = fmaf(av[j][h], acc, dot);
+        }
+        dA[j] = acc;
+      }
+      dot = grp8_sum(dot);
+      float o[F];
+#pragma unroll
+      for (int c = 0; c < F; ++c) o[c] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        if (av[j][h] != 0.0f) {
+          const float dl = av[j][h] * (dA[j] - dot);
+          o[0] = fmaf(dl, x[j][0].x, o[0]); o[1] = fmaf(dl, x[j][0].y, o[1]); o[2] = fmaf(dl, x[j][0].z, o[2]); o[3] = fmaf(dl, x[j][0].w, o[3]);
+          o[4] = fmaf(dl, x[j][1].x, o[4]); o[5] = fmaf(dl, x[j][1].y, o[5]); o[6] = fmaf(dl, x[j][1].z, o[6]); o[7] = fmaf(dl, x[j][1].w, o[7]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < F; ++c) o[c] = grp8_sum(o[c]);
+      if (live && sub == h) {
+        float4* op = reinterpret_cast<float4*>(dq + (i * H + h) * F);
+        op[0] = make_float4(o[0], o[1], o[2], o[3]);
+        op[1] = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  }
+}
+
+template <int H, int NPA>
+static bool launch_attn_slot8_sj(const AttnArgs& a, int SJ, int grid, hipStream_t s, bool bwd) {
+#define DGPPO_SJ(J)                                                                                              \
+  case J:                                                                                                        \
+    if (bwd) hipLaunchKernelGGL((attn_bwd_slot8_kernel<H, NPA, J>), dim3(grid), dim3(256), 0, s, a);             \
+    else hipLaunchKernelGGL((attn_fwd_slot8_kernel<H, NPA, J>), dim3(grid), dim3(256), 0, s, a);                 \
+    return true;
+  switch (SJ) {
+    DGPPO_SJ(1) DGPPO_SJ(2) DGPPO_SJ(3) DGPPO_SJ(4) DGPPO_SJ(5) DGPPO_SJ(6) DGPPO_SJ(7) DGPPO_SJ(8)
+    default: return false;
+  }
+#undef DGPPO_SJ
+}
+// H = 3 heads (the reference's GraphTransformer default, dgppo/nn/gnn.py:81), n <= 32 agents, S <= 64 slots
+static bool launch_attn_slot8(const AttnArgs& a, int grid, hipStream_t s, bool bwd) {
+  if (a.H != 3 || a.H > 8) return false;
+  const int NPA = (a.t.n + 7) / 8, SJ = (a.t.S + 7) / 8;
+  switch (NPA) {
+    case 1: return launch_attn_slot8_sj<3, 1>(a, SJ, grid, s, bwd);
+    case 2: return launch_attn_slot8_sj<3, 2>(a, SJ, grid, s, bwd);
+    case 3: return launch_attn_slot8_sj<3, 3>(a, SJ, grid, s, bwd);
+    case 4: return launch_attn_slot8_sj<3, 4>(a, SJ, grid, s, bwd);
+    default: return false;
+  }
+}
+
 // ---- one wave per graph --------------------------------------------------------------------------------------------
 // For the graph sizes DGPPO uses (n*H <= 32 query rows, <= 96 nodes) a whole graph fits one wave: there is no
 // workgroup barrier anywhere, the 4 waves of a workgroup run 4 independent graphs and other waves fill the stalls.
@@ -1322,7 +1544,10 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
     const int grid = (G + 3) / 4;
     // instantiated for the widths the reference's defaults produce (node features padded to 8, msg_dim 32); other
     // multiples of 4 take the workgroup-per-graph kernels below
-    if (F == 8) launched = launch_attn_wave<8>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
+    // narrow first layer: slot-sparse VALU kernel (one memory round trip per graph); DGPPO_ATTN_DENSE8 forces the MFMA form
+    if (F == 8 && !getenv("DGPPO_ATTN_DENSE8")) launched = launch_attn_slot8(a, grid, (hipStream_t)stream, false);
+    if (launched) {}
+    else if (F == 8) launched = launch_attn_wave<8>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
   }
   if (!launched) {       // workgroup-per-graph fallbacks: MFMA for F % 4 == 0, plain VALU otherwise
@@ -1358,7 +1583,9 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
       !getenv("DGPPO_ATTN_BLOCK")) {
     const int grid = (G + 3) / 4, NP = (d.nH + 7) / 8, SJ = (t.S + 7) / 8;
     a.relu_xo = (relu_xo && dXo) ? 1 : 0;          // fused into the wave kernel's dXo store
-    if (F == 8) launched = launch_attn_wave<8>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
+    if (F == 8 && !dXa && !getenv("DGPPO_ATTN_DENSE8")) launched = launch_attn_slot8(a, grid, (hipStream_t)stream, true);
+    if (launched) {}
+    else if (F == 8) launched = launch_attn_wave<8>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
     a.relu_xo = 0;
   }

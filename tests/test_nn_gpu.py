@@ -537,12 +537,16 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
         dq2, dXa2 = torch.empty_like(dq), torch.empty_like(dXa)
         dXo2 = torch.full_like(dXo, float("nan"))
         K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo, ef, dq2, dXa2, dXo2, G, relu_xo=True)
+        # first-layer form: no input gradient requested (F = 8 takes the slot-sparse VALU kernel by default)
+        dq3 = torch.full((R, H * F), float("nan"), device=cuda)
+        K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo, ef, dq3, None, None, G)
         torch.cuda.synchronize()
         assert torch.equal(dq2, dq) and torch.equal(dXa2, dXa)
         assert torch.equal(dXo2, torch.where(Xo > 0, dXo, torch.zeros_like(dXo))), "relu_xo must equal masking afterwards"
-        return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo)
+        return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo, dq_only=dq3)
 
-    families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "valu": {"DGPPO_ATTN_VALU": "1"}}
+    families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "valu": {"DGPPO_ATTN_VALU": "1"},
+                "dense8": {"DGPPO_ATTN_DENSE8": "1"}}      # F = 8: the matrix-core wave kernels instead of the slot-sparse ones
     outs = {}
     for name, env in families.items():
         for k, v in env.items():
@@ -553,7 +557,8 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
     ref = outs["default"]
     for k, v in ref.items():
         assert torch.isfinite(v).all(), f"default path left non-finite values in {k}"
-    for name in ("block", "valu"):
+    _close(ref["dq_only"], ref["dq"], 2e-5, "dqt-only backward vs full backward")
+    for name in ("block", "valu", "dense8"):
         for k in ref:
             _close(outs[name][k], ref[k], 2e-5, f"{name}.{k}")
 
@@ -591,8 +596,10 @@ def test_attention_wave_kernels_across_topologies(cuda, monkeypatch, kind, n, n_
             dXa = torch.full((R, F), float("nan"), device=cuda)
             dXo = torch.full((G * n_other, F), float("nan"), device=cuda) if n_other > 0 else None
             K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo if n_other > 0 else None, ef, dq, dXa, dXo, G)
+            dq3 = torch.full((R, H * F), float("nan"), device=cuda)           # first-layer form (slot-sparse kernel for F = 8)
+            K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo if n_other > 0 else None, ef, dq3, None, None, G)
             torch.cuda.synchronize()
-            return dict(z=z, at=at, dq=dq, dXa=dXa, **({"dXo": dXo} if dXo is not None else {}))
+            return dict(z=z, at=at, dq=dq, dXa=dXa, dq_only=dq3, **({"dXo": dXo} if dXo is not None else {}))
 
         got = run()
         monkeypatch.setenv("DGPPO_ATTN_VALU", "1")
@@ -756,3 +763,44 @@ def test_policy_and_Vl_with_rnn_options(cuda, rnn_layers, lstm):
     vl.backward(act, dv)
     torch.cuda.synchronize()
     _grad_tree_close(vl, lv, 3e-5)
+
+
+@pytest.mark.parametrize("M,K,N,trans", [(131072, 8, 24, False), (40000, 4, 64, True), (9999, 1, 64, True), (5000, 2, 64, True),
+                                         (777, 16, 192, False), (3000, 7, 10, False), (1, 8, 24, False), (4097, 3, 5, True)])
+def test_dense_small_k_path(cuda, M, K, N, trans):
+    """K <= 16 takes dense_smallk_kernel (W in LDS, a thread per four output columns): plain, bias + relu, accumulate into a
+    strided view, and the ReLU-mask epilogue, against torch fp32 — and against the tiled kernel (DGPPO_DENSE_NO_SMALLK)."""
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M + 31 * K + N)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) if trans else torch.randn(K, N, generator=g)
+    b = torch.randn(N, generator=g)
+    Wm = W.T if trans else W
+    Y = torch.full((M, N), float("nan"), device=cuda)
+    K_.dense_fwd(X.to(cuda), W.to(cuda), b.to(cuda), Y, act=1, trans_w=trans)
+    _close(Y, torch.relu(X @ Wm + b), 2e-6 * math.sqrt(K) + 1e-6, "small-k relu")
+    Y0 = torch.randn(M, N + 6, generator=g)
+    mask = torch.randn(M, N, generator=g)
+    mask[::5] = 0.0
+    Yw = Y0.to(cuda).clone()
+    K_.dense_fwd(X.to(cuda), W.to(cuda), None, Yw[:, 2:2 + N], accumulate=True, trans_w=trans, relu_mask=mask.to(cuda))
+    want = torch.where(mask > 0, Y0[:, 2:2 + N] + X @ Wm, torch.zeros(M, N))
+    _close(Yw[:, 2:2 + N], want, 2e-6 * math.sqrt(K) + 1e-6, "small-k acc+mask")
+    assert torch.equal(Yw[:, :2].cpu(), Y0[:, :2]) and torch.equal(Yw[:, 2 + N:].cpu(), Y0[:, 2 + N:])
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(131072, 8, 24, True), (4096, 16, 64, True), (10001, 3, 8, False), (50000, 8, 24, False)])
+def test_dense_bwd_w_small_k_path(cuda, M, K, N, bias):
+    """K <= 16, N <= 64, N % 4 == 0, M >= 4096: dense_bwd_w_smallk_kernel (register accumulators, LDS atomics per workgroup,
+    common second-stage reduction) against float64."""
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M + K + N)
+    X = torch.randn(M, K, generator=g)
+    dY = torch.randn(M, N, generator=g)
+    dW0 = torch.randn(K, N, generator=g)
+    db0 = torch.randn(N, generator=g)
+    dW, db = dW0.to(cuda).clone(), (db0.to(cuda).clone() if bias else None)
+    K_.dense_bwd_w(X.to(cuda), dY.to(cuda), dW, db)
+    _close(dW, dW0.double() + X.double().T @ dY.double(), 3e-6 * math.sqrt(M), "dW small-k")
+    if bias:
+        _close(db, db0.double() + dY.double().sum(0), 3e-6 * math.sqrt(M), "db small-k")

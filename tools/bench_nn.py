@@ -45,7 +45,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "dense"):
     for (M, Kd, Nd, tr) in [(R, 144, 64, False), (R, 64, 64, False), (R, 64, 192, False), (R, 48, 32, False), (R, 32, 96, False),
                             (R, 8, 24, False), (Ro, 8, 32, False), (R, 64, 144, True), (R, 192, 64, True), (R, 64, 64, True),
-                            (R, 64, 4, False), (32768, 144, 64, False), (32768, 64, 64, False), (32768, 64, 192, False)]:
+                            (R, 64, 4, False), (R, 4, 64, True), (R, 1, 64, True), (32768, 8, 24, False), (32768, 144, 64, False), (32768, 64, 64, False), (32768, 64, 192, False)]:
         dense_case(M, Kd, Nd, tr)
 if which in ("all", "elem"):
     x = torch.randn(R, 64, device=dev); g = torch.ones(64, device=dev); b = torch.zeros(64, device=dev)
@@ -73,6 +73,8 @@ if which in ("all", "attn"):
             timeit(f"attn_fwd G={G} F={F}", lambda: K.attn_fwd(cfg, F, 3, Kp, qt, Xa, Xo, ef, em, z, at, G))
             dq = torch.empty_like(qt); dXa = torch.empty_like(Xa); dXo = torch.empty_like(Xo)
             timeit(f"attn_bwd G={G} F={F}", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, dXa, dXo, G))
+            if F == 8:    # the first layer needs no input gradient
+                timeit(f"attn_bwd G={G} F={F} (dqt only)", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, None, None, G))
 if which in ("all", "fused"):
     for M, train in ((32768, False), (131072, False), (131072, True)):
         X = torch.randn(M, 64, device=dev)
