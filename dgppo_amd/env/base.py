@@ -211,8 +211,18 @@ class MultiAgentEnv(ABC):
     def get_graph(self, env_state, lidar_data=None) -> GraphsTuple:
         raise NotImplementedError
 
-    def render_video(self, *args, **kwargs):
-        raise NotImplementedError("rendering is outside the hot-path scope of this build (SURVEY §2 row 22)")
+    def render_video(self, rollout, video_path, Ta_is_unsafe=None, viz_opts: Optional[dict] = None, dpi: int = 100, **kwargs):
+        """One episode as an animation (dgppo/env/lidar_env/base.py:209-221, dgppo/env/mpe/base.py render_video).  `rollout`
+        holds one episode ([T, ...]) or a batch ([B, T, ...], pass index=b).  Returns the path written (`.gif` when no
+        ffmpeg binary is available for `.mp4`)."""
+        from . import plot
+        p = self._params
+        common = dict(rollout=rollout, video_path=video_path, side_length=self.area_size, dim=2, n_agent=self.num_agents,
+                      r=p["car_radius"], cost_components=self.cost_components, Ta_is_unsafe=Ta_is_unsafe, viz_opts=viz_opts,
+                      n_goal=self.num_goals, dpi=dpi, **kwargs)
+        if self.cfg.is_lidar:
+            return plot.render_lidar(n_rays=self.cfg.top_k if self.cfg.n_obs > 0 else 0, **common)
+        return plot.render_mpe(n_obs=self.cfg.n_obs, obs_r=p.get("obs_radius", 0.05), **common)
 
 
 def _sq_tree(v):

@@ -3,9 +3,12 @@
 `{path}/config.yaml` and `{path}/models/{step}/{actor,Vl,Vh}.pkl`, run `--epi` test episodes with the deterministic
 (or `--stochastic`) policy, print per-episode reward / cost / safe rate and the aggregate, optionally append
 `test_log.csv`.  All episodes run as ONE batched rollout on the GPU (the reference loops over episodes on the host).
-Rendering (`render_video`) is not built: videos are skipped with a notice."""
+Unless `--no-video`, every episode is rendered to `{path}/videos/{step}/` (test.py:150-159; `.gif` when no ffmpeg binary
+is available for `.mp4`)."""
 import argparse
+import datetime
 import os
+import pathlib
 
 import numpy as np
 
@@ -54,7 +57,15 @@ def test(args):
         with open(os.path.join(args.path, "test_log.csv"), "a") as f:
             f.write(EV.csv_line(env, args.epi, agg))
     if not args.no_video:
-        print("(videos skipped: rendering is not part of this build — pass --no-video to silence this notice)")
+        videos_dir = pathlib.Path(args.path) / "videos" / f"{step}"
+        videos_dir.mkdir(exist_ok=True, parents=True)
+        stamp = datetime.datetime.now().strftime("%m%d-%H%M")
+        unsafe = (ro.costs >= 0.0).any(dim=-1).cpu().numpy()          # [B, T, n]  (test.py:103-105)
+        for i in range(len(keys)):
+            name = (f"n{num_agents}_epi{i:02}_reward{stats['reward'][i]:.3f}_cost{stats['cost'][i]:.3f}"
+                    f"_sr{stats['safe_rate'][i] * 100:.0f}")
+            out = env.render_video(ro, videos_dir / f"{stamp}_{name}.mp4", unsafe[i], {}, dpi=args.dpi, index=i)
+            print(f"video: {out}")
     return agg
 
 

@@ -182,6 +182,29 @@ def test_test_py_cli_after_train(cuda, tmp_path):
     sout = subprocess.run(tcmd[:-4] + ["--stochastic", "--max-step", "32", "--no-video"], capture_output=True, text=True,
                           timeout=600, cwd=ROOT)
     assert sout.returncode == 0 and "epi: 4, reward:" in sout.stdout, sout.stderr[-2000:]
+    # without --no-video every episode is rendered (test.py:150-159): one animation per episode under videos/{step}/, built
+    # from the GraphsTuples the materialise kernel emits for the stored rollout
+    vcmd = [sys.executable, os.path.join(ROOT, "test.py"), "--path", str(run_dir), "--epi", "2", "--max-step", "6", "--dpi", "30"]
+    vout = subprocess.run(vcmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert vout.returncode == 0, vout.stderr[-2000:]
+    vids = sorted(os.listdir(run_dir / "videos" / "1"))
+    assert len(vids) == 2 and all("_n3_epi0" in v and v.endswith((".gif", ".mp4")) for v in vids), vids
+    if vids[0].endswith(".gif"):
+        from PIL import Image, ImageSequence
+        with Image.open(run_dir / "videos" / "1" / vids[0]) as im:
+            assert sum(1 for _ in ImageSequence.Iterator(im)) == 6
+
+
+def test_env_render_video_mpe(cuda, tmp_path):
+    """env.render_video on a batched MPE rollout straight from the engine (disc obstacles, index= picks the episode)."""
+    from dgppo.algo import make_algo
+    from dgppo.env import make_env
+    env = make_env("MPESpread", 3, num_obs=2, max_step=4)
+    algo = make_algo(algo="dgppo", env=env, node_dim=env.node_dim, edge_dim=env.edge_dim, state_dim=env.state_dim,
+                     action_dim=env.action_dim, n_agents=env.num_agents, n_env_train=2, batch_size=8, seed=0)
+    ro = algo.collect_deterministic(np.array([5, 6], dtype=np.int64), env=env)
+    out = env.render_video(ro, tmp_path / "mpe.gif", None, {}, dpi=30, index=1)
+    assert out.exists() and out.stat().st_size > 500
 
 
 def test_informarl_algo_round_trip(cuda, tmp_path):
