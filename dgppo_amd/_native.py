@@ -16,10 +16,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DGPPO_HIP_LIB: developer override (the stamps build of tools/stamps_wave.py); the default is the in-tree library
 LIB_PATH = os.environ.get("DGPPO_HIP_LIB") or os.path.join(_HERE, "csrc", "libdgppo_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OPT_STATE_FLOATS = 8 + 2 * 256     # DGPPO_OPT_STATE_FLOATS (include/dgppo_hip.h)
 
-ENV_KINDS = {"LidarSpread": 0, "LidarTarget": 1, "LidarBicycleTarget": 2, "MPESpread": 3, "MPETarget": 4}
+ENV_KINDS = {"LidarSpread": 0, "LidarTarget": 1, "LidarBicycleTarget": 2, "MPESpread": 3, "MPETarget": 4,
+             "LidarLine": 5, "MPELine": 6, "MPEFormation": 7, "MPECorridor": 8, "MPEConnectSpread": 9}
+GOALS_NODES, GOALS_LINE, GOALS_LINE_INTERIOR, GOALS_CIRCLE = range(4)
 RECT_STRIDE = 16
 
 
@@ -32,16 +34,18 @@ class EnvCfg(C.Structure):
         ("obs_radius", C.c_float), ("dist2goal", C.c_float), ("two_car_radius", C.c_float),
         ("lidar_mask_radius", C.c_float), ("eye_offset", C.c_float), ("car_plus_obs", C.c_float),
         ("vel_limit", C.c_float), ("reset_min_dist", C.c_float),
+        ("reward_goals", C.c_int32), ("n_cost", C.c_int32), ("obs_mask_radius", C.c_float), ("y_limit", C.c_float),
+        ("connect_radius", C.c_float), ("reset_side_y", C.c_float), ("goal_shift_y", C.c_float), ("line_min_dist", C.c_float),
     ]
 
     # ---- derived sizes (mirror csrc/common.h) ----
     @property
     def is_lidar(self):
-        return self.kind <= 2
+        return self.kind <= 2 or self.kind == 5
 
     @property
     def is_spread(self):
-        return self.kind in (0, 3)
+        return self.kind not in (1, 2, 4)
 
     @property
     def obs_nodes(self):
@@ -76,15 +80,28 @@ class EnvCfg(C.Structure):
         return RECT_STRIDE if self.is_lidar else self.state_dim
 
 
-def make_env_cfg(kind: int, n_agents: int, n_obs: int, n_rays: int = 32, top_k: int = 8, area_size: float = 1.5,
-                 dt: float = 0.03, car_radius: float = 0.05, comm_radius: float = 0.5, obs_radius: float = 0.05,
-                 dist2goal: float = 0.01) -> EnvCfg:
+def make_env_cfg(kind: int, n_agents: int, n_obs: int, n_rays: int = 32, top_k: int = 8, area_size: float = None,
+                 dt: float = 0.03, car_radius: float = 0.05, comm_radius: float = 0.5, obs_radius: float = None,
+                 dist2goal: float = 0.01, connect_radius: float = 0.45, corridor_width: float = 0.2) -> EnvCfg:
     """Thresholds are formed in Python doubles then rounded to fp32, exactly as the reference's weakly-typed
-    Python floats are (e.g. `comm_radius - 1e-1`, dgppo/env/lidar_env/lidar_spread.py:88)."""
-    is_lidar = kind <= 2
+    Python floats are (e.g. `comm_radius - 1e-1`, dgppo/env/lidar_env/lidar_spread.py:88).  area_size / obs_radius default
+    to the PARAMS of the kind (1.5 / 0.05; MPECorridor and MPEConnectSpread: area 1.0, obs_radius derived / 0.25)."""
+    is_lidar = kind <= 2 or kind == 5
+    corridor, connect = kind == 8, kind == 9
+    if area_size is None:
+        area_size = 1.0 if (corridor or connect) else 1.5
+    if corridor:
+        n_obs = 2                                                          # mpe_corridor.py:35-37
+        obs_radius = (area_size - corridor_width) / 4                      # :39
+    elif connect:
+        n_obs = 1                                                          # mpe_connect_spread.py:38-40
+        obs_radius = 0.25 if obs_radius is None else obs_radius
+    elif obs_radius is None:
+        obs_radius = 0.05
     sd = 5 if kind == 2 else 4
     c = EnvCfg()
-    c.kind, c.n_agents, c.n_goals, c.n_obs = kind, n_agents, n_agents, n_obs
+    c.kind, c.n_agents, c.n_obs = kind, n_agents, n_obs
+    c.n_goals = 2 if kind in (5, 6) else (1 if kind == 7 else n_agents)
     c.n_rays, c.top_k = (n_rays, top_k) if is_lidar else (0, 0)
     c.state_dim, c.node_dim = sd, sd + 3
     c.area_size, c.dt, c.car_radius, c.comm_radius = area_size, dt, car_radius, comm_radius
@@ -94,7 +111,19 @@ def make_env_cfg(kind: int, n_agents: int, n_obs: int, n_rays: int = 32, top_k: 
     c.eye_offset = comm_radius + 1
     c.car_plus_obs = car_radius + obs_radius
     c.vel_limit = 0.5 if is_lidar else 1.0
-    c.reset_min_dist = (2.2 * car_radius) if is_lidar else (2 * car_radius)
+    c.reset_min_dist = (2.2 * car_radius) if (is_lidar and kind != 5) else ((2.3 if connect else 2) * car_radius)
+    # ---- task variants ----
+    c.reward_goals = {5: GOALS_LINE, 6: GOALS_LINE if n_agents > 3 else GOALS_LINE_INTERIOR, 7: GOALS_CIRCLE}.get(kind, GOALS_NODES)
+    c.n_cost = 3 if connect else 2
+    c.obs_mask_radius = comm_radius * 100 if (corridor or connect) else comm_radius
+    c.y_limit = area_size * 2 if (corridor or connect) else area_size
+    c.connect_radius = connect_radius
+    c.reset_side_y = ((area_size - obs_radius * 2) / 2 - 1.5 * car_radius) if (corridor or connect) else area_size
+    c.goal_shift_y = (area_size - (area_size - obs_radius * 2) / 2 + 1.5 * car_radius) if (corridor or connect) else 0.0
+    if kind in (5, 6):
+        c.line_min_dist = n_agents * 5 * car_radius if (kind == 6 and n_agents <= 3) else (n_agents - 2) * 6 * car_radius
+    else:
+        c.line_min_dist = 0.0
     return c
 
 

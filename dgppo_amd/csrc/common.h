@@ -30,9 +30,20 @@ void dgppo_set_error(const char* fmt, ...);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- env config helpers (host + device) ------------------------------------------------------
-__host__ __device__ inline bool cfg_is_lidar(const dgppo_env_cfg& c) { return c.kind <= DGPPO_ENV_LIDAR_BICYCLE_TARGET; }
+__host__ __device__ inline bool cfg_is_lidar(const dgppo_env_cfg& c) {
+  return c.kind <= DGPPO_ENV_LIDAR_BICYCLE_TARGET || c.kind == DGPPO_ENV_LIDAR_LINE;
+}
+// every agent is connected to every goal node (Spread and its subclasses) vs to its own goal (Target)
 __host__ __device__ inline bool cfg_is_spread(const dgppo_env_cfg& c) {
-  return c.kind == DGPPO_ENV_LIDAR_SPREAD || c.kind == DGPPO_ENV_MPE_SPREAD;
+  return c.kind != DGPPO_ENV_LIDAR_TARGET && c.kind != DGPPO_ENV_LIDAR_BICYCLE_TARGET && c.kind != DGPPO_ENV_MPE_TARGET;
+}
+// the five base kinds with their own goal nodes as reward goals: what the specialised LiDAR kernels assume
+__host__ __device__ inline bool cfg_is_base_kind(const dgppo_env_cfg& c) {
+  return c.kind <= DGPPO_ENV_MPE_TARGET && c.n_goals == c.n_agents && c.reward_goals == DGPPO_GOALS_NODES && c.n_cost == 2;
+}
+// positions the reward measures against: n derived goals, or the goal nodes
+__host__ __device__ inline int cfg_reward_goals(const dgppo_env_cfg& c) {
+  return c.reward_goals == DGPPO_GOALS_NODES ? c.n_goals : c.n_agents;
 }
 __host__ __device__ inline bool cfg_is_bicycle(const dgppo_env_cfg& c) { return c.kind == DGPPO_ENV_LIDAR_BICYCLE_TARGET; }
 // nodes that carry obstacle information: n*k LiDAR hit nodes or n_obs disc nodes

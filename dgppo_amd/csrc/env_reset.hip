@@ -18,6 +18,9 @@ struct ResetArgs {
   float* goal;
   float* obst;
   int B;
+  // task variants: thresholds formed on the host in double from the fp32 PARAMS and rounded once (oracle: reset_thresholds)
+  float form_lo, form_hi;     // MPEFormation landmark box: comm_radius + 2 car_radius .. area - comm_radius - 2 car_radius
+  float line_obs_margin;      // LidarLine: 1.1 car_radius
 };
 
 struct Stream {
@@ -45,7 +48,7 @@ __device__ inline bool rect_inside_r(const float* rec, float px, float py, float
 
 // One rejection-sampled node (get_node / non_valid_node, env/utils.py:160-172): redraw until it is farther than
 // min_dist from every row of `all` (unfilled rows are zeros) and outside every inflated rectangle, or max_iter tries.
-__device__ __noinline__ void sample_node(Stream& st, float* all, int n, int SD, float A, float min_dist, float half,
+__device__ __noinline__ void sample_node(Stream& st, float* all, int n, int SD, float A, float Ay, float min_dist, float half,
                                          const float* rects, int no, int max_iter, int slot, int& n_iter) {
   int it = 0;
   float cx = 0.0f, cy = 0.0f;
@@ -53,7 +56,7 @@ __device__ __noinline__ void sample_node(Stream& st, float* all, int n, int SD, 
     float u0, u1;
     st.uniform2(u0, u1);
     cx = u0 * A;
-    cy = u1 * A;
+    cy = u1 * Ay;
     float dmin = 3.4e38f;
     for (int j = 0; j < n; ++j) {
       float dx = all[j * SD] - cx, dy = all[j * SD + 1] - cy;
@@ -72,6 +75,190 @@ __device__ __noinline__ void sample_node(Stream& st, float* all, int n, int SD, 
 }
 
 #define MAX_AGENTS 64
+
+// ---- task variants (lidar_line.py:39-129, mpe_line.py:36-122, mpe_formation.py:37-92, mpe_corridor.py:41-60,
+//      mpe_connect_spread.py:50-107): same stream, statement order of oracle/env_np.py::_reset_variant -------------------
+// positions the reward measures against (the same arithmetic as env_step.hip phase 1a / oracle reward_goal_positions)
+__device__ inline void reward_goal(const dgppo_env_cfg& c, const float* lm, int SD, int g, float& gx, float& gy) {
+  const int n = c.n_agents;
+  if (c.reward_goals == DGPPO_GOALS_CIRCLE) {
+    const float th = ((float)g / (float)n) * 6.28318530717958647692f;
+    gx = lm[0] + c.comm_radius * cosf(th);
+    gy = lm[1] + c.comm_radius * sinf(th);
+  } else {
+    const bool ends = c.reward_goals == DGPPO_GOALS_LINE;
+    const float i_f = ends ? (float)g : (float)(g + 1), den = ends ? (float)(n - 1) : (float)(n + 1);
+    gx = lm[0] + (i_f * (lm[SD] - lm[0])) / den;
+    gy = lm[1] + (i_f * (lm[SD + 1] - lm[1])) / den;
+  }
+}
+
+// nearest-neighbour distance of row i among the n rows of p (+1e6 on the diagonal, mpe_connect_spread.py:54-56)
+__device__ inline float nn_dist(const float* p, int n, int SD, int i) {
+  float m = 3.4e38f;
+  for (int j = 0; j < n; ++j) {
+    const float dx = p[i * SD] - p[j * SD], dy = p[i * SD + 1] - p[j * SD + 1];
+    m = fminf(m, sqrtf(dx * dx + dy * dy) + ((i == j) ? 1e6f : 0.0f));
+  }
+  return m;
+}
+
+__global__ void env_reset_variant_kernel(ResetArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const dgppo_env_cfg& c = a.cfg;
+  const int n = c.n_agents, ng = c.n_goals, no = c.n_obs, SD = c.state_dim;
+  const bool lidar = cfg_is_lidar(c);
+  const float A = c.area_size;
+  const uint64_t seed = a.seeds[b];
+  Stream st;
+  st.k0 = (uint32_t)seed; st.k1 = (uint32_t)(seed >> 32); st.d = 0;
+  float* agent = a.agent + (size_t)b * n * SD;
+  float* goal = a.goal + (size_t)b * ng * SD;
+  float* obst = a.obst ? a.obst + (size_t)b * no * cfg_obst_stride(c) : nullptr;
+  // work array for the goals get_node_goal_rng samples next to the agents: the kinds with n goal nodes use the output
+  // rows; Line / Formation discard those goals (states, _ = get_node_goal_rng(...)): positions only, in LDS
+  __shared__ float s_discard[64][MAX_AGENTS * 2];
+  const bool own_goals = (ng == n);
+  float* sgoal = own_goals ? goal : s_discard[threadIdx.x];
+  const int GS = own_goals ? SD : 2;                  // row stride of sgoal
+  const float min_dist = c.reset_min_dist, half = min_dist / 2.0f;
+  const int max_iter = 1024;
+  const bool connect = c.kind == DGPPO_ENV_MPE_CONNECT_SPREAD;
+  // ---- agents (and sampled goals): bounded restarts, and for ConnectSpread the bounded connectivity rejection ----
+  for (int outer = 0; outer < (connect ? 4096 : 1); ++outer) {
+    for (int attempt = 0; attempt < 64; ++attempt) {
+      for (int i = 0; i < n * SD; ++i) agent[i] = 0.0f;
+      for (int i = 0; i < n * GS; ++i) sgoal[i] = 0.0f;
+      bool failed = false;
+      for (int i = 0; i < n; ++i) {
+        int it_a = 0, it_g = 0;
+        sample_node(st, agent, n, SD, A, c.reset_side_y, min_dist, half, nullptr, 0, max_iter, i, it_a);
+        sample_node(st, sgoal, n, GS, A, c.reset_side_y, min_dist, half, nullptr, 0, max_iter, i, it_g);
+        if (it_a >= max_iter || it_g >= max_iter) { failed = true; break; }
+      }
+      if (!failed) break;
+    }
+    if (!connect) break;
+    bool bad = false;
+    for (int i = 0; i < n; ++i) {
+      const float mda = nn_dist(agent, n, SD, i), mdg = nn_dist(sgoal, n, GS, i);
+      bad = bad || (mda > c.connect_radius) || (mda < c.two_car_radius) || (mdg > c.connect_radius);
+    }
+    if (!bad) break;
+  }
+  if (c.kind == DGPPO_ENV_MPE_CORRIDOR || connect) {
+    for (int i = 0; i < n; ++i) goal[i * SD + 1] = goal[i * SD + 1] + c.goal_shift_y;
+    if (connect) {                                   // one large disc, x uniform (mpe_connect_spread.py:91-95)
+      float u0, u1;
+      st.uniform2(u0, u1);
+      for (int d = 0; d < SD; ++d) obst[d] = 0.0f;
+      obst[0] = c.obs_radius + u0 * ((A - c.obs_radius) - c.obs_radius);
+      obst[1] = A / 2.0f;
+    } else {                                         // the two corridor walls (mpe_corridor.py:55-56)
+      for (int d = 0; d < 2 * SD; ++d) obst[d] = 0.0f;
+      obst[0] = c.obs_radius; obst[1] = A / 2.0f;
+      obst[SD] = A - c.obs_radius; obst[SD + 1] = A / 2.0f;
+    }
+    return;
+  }
+  // ---- landmarks ----
+  for (int i = 0; i < ng * SD; ++i) goal[i] = 0.0f;
+  if (c.kind == DGPPO_ENV_MPE_FORMATION) {
+    const float lo = a.form_lo, hi = a.form_hi;
+    float u0, u1;
+    st.uniform2(u0, u1);
+    goal[0] = lo + u0 * (hi - lo);
+    goal[1] = lo + u1 * (hi - lo);
+  } else {
+    const float md = c.line_min_dist;
+    float u0, u1;
+    if (c.kind == DGPPO_ENV_MPE_LINE && n <= 3) {
+      st.uniform2(u0, u1);
+      goal[0] = u0 * A; goal[1] = u1 * A;
+    } else {
+      const float side = A - md;
+      st.uniform2(u0, u1);
+      const float cx = u0 * (A - side) - A / 2.0f;
+      const float cy = u1 * side + (A / 2.0f - side);
+      st.uniform2(u0, u1);
+      int region = (int)(u0 * 4.0f);
+      region = region > 3 ? 3 : region;
+      float rx, ry;                                  // exact quarter turns (see oracle/_reset_variant)
+      if (region == 0) { rx = cx; ry = cy; } else if (region == 1) { rx = -cy; ry = cx; }
+      else if (region == 2) { rx = -cx; ry = -cy; } else { rx = cy; ry = -cx; }
+      goal[0] = rx + A / 2.0f; goal[1] = ry + A / 2.0f;
+    }
+    for (int it = 0; it < 100000; ++it) {
+      st.uniform2(u0, u1);
+      goal[SD] = u0 * A; goal[SD + 1] = u1 * A;
+      const float dx = goal[SD] - goal[0], dy = goal[SD + 1] - goal[1];
+      if (!(sqrtf(dx * dx + dy * dy) < md)) break;
+    }
+  }
+  // ---- obstacles: keep clear of the agents and of the n reward goals ----
+  if (lidar) {
+    const float r_in = a.line_obs_margin;
+    for (int o = 0; o < no; ++o) {
+      float* rec = obst + o * DGPPO_RECT_STRIDE;
+      for (int it = 0; it < 100000; ++it) {
+        float u0, u1;
+        st.uniform2(u0, u1);
+        const float cx = u0 * A, cy = u1 * A;
+        st.uniform2(u0, u1);
+        const float lo = 0.1f, hi = 0.3f;
+        const float w = lo + u0 * (hi - lo), h = lo + u1 * (hi - lo);
+        st.uniform2(u0, u1);
+        const float th = u0 * 3.14159265358979323846f;
+        const float cs = cosf(th), sn = sinf(th);
+        rec[0] = cx; rec[1] = cy; rec[2] = w; rec[3] = h; rec[4] = th; rec[5] = cs; rec[6] = sn; rec[7] = 0.0f;
+        const float hw = w / 2.0f, hh = h / 2.0f;
+        const float bx[4] = {hw, -hw, -hw, hw};
+        const float by[4] = {hh, hh, -hh, -hh};
+        for (int m = 0; m < 4; ++m) {
+          rec[8 + 2 * m] = (cs * bx[m] + (-sn) * by[m]) + cx;
+          rec[9 + 2 * m] = (sn * bx[m] + cs * by[m]) + cy;
+        }
+        bool inside = false;
+        for (int i = 0; i < n; ++i) inside = inside || rect_inside_r(rec, agent[i * SD], agent[i * SD + 1], r_in);
+        for (int g = 0; g < n; ++g) {
+          float gx, gy;
+          reward_goal(c, goal, SD, g, gx, gy);
+          inside = inside || rect_inside_r(rec, gx, gy, r_in);
+        }
+        if (!inside) break;
+      }
+    }
+  } else {
+    const float lo = c.car_radius * 3.0f;
+    const float hi = A - c.car_radius * 3.0f;
+    const float thr_g = c.two_car_radius + c.obs_radius;
+    for (int o = 0; o < no; ++o) {
+      bool first = true;
+      float cx = 0.0f, cy = 0.0f;
+      for (int it = 0; it < 100000; ++it) {
+        float u0, u1;
+        st.uniform2(u0, u1);
+        if (first) { cx = u0 * A; cy = u1 * A; first = false; }
+        else { cx = lo + u0 * (hi - lo); cy = lo + u1 * (hi - lo); }
+        float da = 3.4e38f, dg = 3.4e38f;
+        for (int j = 0; j < n; ++j) {
+          float dx = agent[j * SD] - cx, dy = agent[j * SD + 1] - cy;
+          da = fminf(da, sqrtf(dx * dx + dy * dy));
+          float gx, gy;
+          reward_goal(c, goal, SD, j, gx, gy);
+          dx = gx - cx; dy = gy - cy;
+          dg = fminf(dg, sqrtf(dx * dx + dy * dy));
+        }
+        const bool bad = (da <= c.car_plus_obs) || (dg <= thr_g) || (cx < lo) || (cy < lo) || (cx > hi) || (cy > hi);
+        if (!bad) break;
+      }
+      for (int d = 0; d < SD; ++d) obst[o * SD + d] = 0.0f;
+      obst[o * SD] = cx; obst[o * SD + 1] = cy;
+    }
+  }
+}
+
 
 __global__ void env_reset_kernel(ResetArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,8 +313,8 @@ __global__ void env_reset_kernel(ResetArgs a) {
     bool failed = false;
     for (int i = 0; i < n; ++i) {
       int it_a = 0, it_g = 0;
-      sample_node(st, agent, n, SD, A, min_dist, half, lidar ? obst : nullptr, no, max_iter, i, it_a);
-      sample_node(st, goal, n, SD, A, min_dist, half, lidar ? obst : nullptr, no, max_iter, i, it_g);
+      sample_node(st, agent, n, SD, A, A, min_dist, half, lidar ? obst : nullptr, no, max_iter, i, it_a);
+      sample_node(st, goal, n, SD, A, A, min_dist, half, lidar ? obst : nullptr, no, max_iter, i, it_g);
       if (it_a >= max_iter || it_g >= max_iter) { failed = true; break; }
     }
     if (!failed) break;
@@ -180,7 +367,16 @@ extern "C" int32_t dgppo_env_reset(const dgppo_env_cfg* cfg, const uint64_t* see
   DGPPO_REQUIRE(cfg->n_agents <= MAX_AGENTS, "reset supports at most %d agents", MAX_AGENTS);
   ResetArgs a;
   a.cfg = *cfg; a.seeds = seeds; a.agent = agent; a.goal = goal; a.obst = obst; a.B = B;
-  hipLaunchKernelGGL(env_reset_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, a);
+  a.form_lo = (float)((double)cfg->comm_radius + 2.0 * (double)cfg->car_radius);
+  a.form_hi = (float)((double)cfg->area_size - (double)cfg->comm_radius - 2.0 * (double)cfg->car_radius);
+  a.line_obs_margin = (float)((double)cfg->car_radius * 1.1);
+  if (cfg->kind >= DGPPO_ENV_LIDAR_LINE) {
+    DGPPO_REQUIRE(!(cfg->kind == DGPPO_ENV_LIDAR_LINE || (cfg->kind == DGPPO_ENV_MPE_LINE && cfg->n_agents > 3)) ||
+                      cfg->area_size - cfg->line_min_dist >= 0.0f,
+                  "The area size is too small to place the landmarks.");      // lidar_line.py:56-57
+    hipLaunchKernelGGL(env_reset_variant_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, a);
+  } else
+    hipLaunchKernelGGL(env_reset_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, a);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

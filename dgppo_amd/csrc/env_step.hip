@@ -39,11 +39,14 @@ __global__ void env_step_kernel(StepArgs a) {
   float* s_alpha = s_hnext + n * kk * 2;    // n*R
   float* s_fa = s_alpha + (lidar ? n * R : 0);  // n*4   state2feat(next agent)
   float* s_fg = s_fa + n * 4;               // ng*4
-  float* s_d2g = s_fg + ng * 4;             // ng
-  float* s_an2 = s_d2g + ng;                // n
+  const int nrg = cfg_reward_goals(c);      // positions the reward measures against (the goal nodes, or n derived goals)
+  float* s_d2g = s_fg + ng * 4;             // nrg
+  float* s_an2 = s_d2g + nrg;               // n
   float* s_isin = s_an2 + n;                // n (0/1)
-  float* s_ino = s_isin + n;                // n*no
-  float* s_pair = s_ino + n * no;           // n*n + n*max(kk,no) + ng*n
+  float* s_md = s_isin + n;                 // n   nearest-neighbour distance of each agent (connectivity cost)
+  float* s_rg = s_md + n;                   // nrg*2 reward goal positions
+  float* s_ino = s_rg + nrg * 2;            // n*no
+  float* s_pair = s_ino + n * no;           // n*n + n*max(kk,no) + nrg*n
 
   const bool do_dyn = (a.mode == MODE_STEP);
   const bool do_sense = (a.mode != MODE_GRAPH) && lidar && no > 0;
@@ -77,7 +80,7 @@ __global__ void env_step_kernel(StepArgs a) {
       } else {        // lidar_env/base.py:146-149
         const float vl = c.vel_limit;
         nx[0] = clampf(x[2] * dt + x[0], 0.0f, A);
-        nx[1] = clampf(x[3] * dt + x[1], 0.0f, A);
+        nx[1] = clampf(x[3] * dt + x[1], 0.0f, c.y_limit);       // = A except MPECorridor / MPEConnectSpread (2 A)
         nx[2] = clampf((u0 * 10.0f) * dt + x[2], -vl, vl);
         nx[3] = clampf((u1 * 10.0f) * dt + x[3], -vl, vl);
       }
@@ -92,6 +95,24 @@ __global__ void env_step_kernel(StepArgs a) {
   for (int g = tid - 64; g >= 0 && g < ng; g += nt) state2feat<SD>(s_goal + g * SD, s_fg + g * 4);
   if (nt <= 64)
     for (int g = tid; g < ng; g += nt) state2feat<SD>(s_goal + g * SD, s_fg + g * 4);
+  // reward goals (landmark2goal: lidar_line.py:131-136, mpe_line.py:124-133, mpe_formation.py:94-98)
+  if (do_dyn)
+    for (int g = tid; g < nrg; g += nt) {
+      float gx, gy;
+      if (c.reward_goals == DGPPO_GOALS_NODES) { gx = s_goal[g * SD]; gy = s_goal[g * SD + 1]; }
+      else if (c.reward_goals == DGPPO_GOALS_CIRCLE) {
+        const float th = ((float)g / (float)n) * 6.28318530717958647692f;
+        gx = s_goal[0] + c.comm_radius * cosf(th);
+        gy = s_goal[1] + c.comm_radius * sinf(th);
+      } else {
+        const bool ends = c.reward_goals == DGPPO_GOALS_LINE;
+        const float i_f = ends ? (float)g : (float)(g + 1), den = ends ? (float)(n - 1) : (float)(n + 1);
+        const float dx = s_goal[SD] - s_goal[0], dy = s_goal[SD + 1] - s_goal[1];
+        gx = s_goal[0] + (i_f * dx) / den;
+        gy = s_goal[1] + (i_f * dy) / den;
+      }
+      s_rg[g * 2] = gx; s_rg[g * 2 + 1] = gy;
+    }
   __syncthreads();
 
   // ---- phase 1b: all pairwise distances in parallel (one correctly-rounded sqrt per thread) --------------
@@ -99,7 +120,7 @@ __global__ void env_step_kernel(StepArgs a) {
   // s_ino : [n*no] start-inside-rectangle flags of the t+1 positions (env/utils.py:117, r = 0)
   {
     const int oc = lidar ? kk : no;
-    const int n_aa = do_dyn ? n * n : 0, n_ao = do_dyn ? n * oc : 0, n_ga = (do_dyn && spread) ? ng * n : (do_dyn ? ng : 0);
+    const int n_aa = do_dyn ? n * n : 0, n_ao = do_dyn ? n * oc : 0, n_ga = (do_dyn && spread) ? nrg * n : (do_dyn ? nrg : 0);
     const int n_in = do_sense ? n * no : 0;
     for (int idx = tid; idx < n_aa + n_ao + n_ga + n_in; idx += nt) {
       if (idx < n_aa) {
@@ -116,7 +137,7 @@ __global__ void env_step_kernel(StepArgs a) {
         const int q = idx - n_aa - n_ao;
         int g, j;
         if (spread) { g = q / n; j = q - g * n; } else { g = q; j = q; }   // each goal finds the nearest agent / paired goal
-        float dx = s_goal[g * SD] - s_agent[j * SD], dy = s_goal[g * SD + 1] - s_agent[j * SD + 1];
+        float dx = s_rg[g * 2] - s_agent[j * SD], dy = s_rg[g * 2 + 1] - s_agent[j * SD + 1];
         s_pair[idx] = sqrtf(dx * dx + dy * dy);
       } else {
         const int q = idx - n_aa - n_ao - n_ga, i = q / no, o = q - i * no;
@@ -143,20 +164,21 @@ __global__ void env_step_kernel(StepArgs a) {
         }
         float c0 = (agent_cost <= 0.0f) ? agent_cost - 0.5f : agent_cost + 0.5f;
         float c1 = (obs_cost <= 0.0f) ? obs_cost - 0.5f : obs_cost + 0.5f;
-        if (lidar) { c0 = clampf_nan(c0, -1.0f, 1.0f); c1 = clampf_nan(c1, -1.0f, 1.0f); }
+        if (lidar || c.kind == DGPPO_ENV_MPE_CONNECT_SPREAD) { c0 = clampf_nan(c0, -1.0f, 1.0f); c1 = clampf_nan(c1, -1.0f, 1.0f); }
         else { c0 = fmaxf(c0, -1.0f); c1 = fmaxf(c1, -1.0f); }   // mpe/base.py:189 clips only from below
-        a.cost[((size_t)b * n + i) * 2] = c0;
-        a.cost[((size_t)b * n + i) * 2 + 1] = c1;
+        a.cost[((size_t)b * n + i) * c.n_cost] = c0;
+        a.cost[((size_t)b * n + i) * c.n_cost + 1] = c1;
+        s_md[i] = md;
       }
     }
     if (do_dyn) {
-      for (int g = tid - 64; g >= 0 && g < ng; g += nt) {
+      for (int g = tid - 64; g >= 0 && g < nrg; g += nt) {
         float d2g = s_pair[n_aa + n_ao + (spread ? g * n : g)];
         if (spread) for (int j = 1; j < n; ++j) d2g = nanmin(d2g, s_pair[n_aa + n_ao + g * n + j]);
         s_d2g[g] = d2g;
       }
       if (nt <= 64)
-        for (int g = tid; g < ng; g += nt) {
+        for (int g = tid; g < nrg; g += nt) {
           float d2g = s_pair[n_aa + n_ao + (spread ? g * n : g)];
           if (spread) for (int j = 1; j < n; ++j) d2g = nanmin(d2g, s_pair[n_aa + n_ao + g * n + j]);
           s_d2g[g] = d2g;
@@ -165,17 +187,28 @@ __global__ void env_step_kernel(StepArgs a) {
   }
   __syncthreads();
 
+  if (do_dyn && c.n_cost == 3 && tid < n) {
+    // connectivity (mpe_connect_spread.py:115-117): the largest nearest-neighbour distance against connect_radius, the same
+    // value for every agent; NaN propagates like jnp.max
+    float w = s_md[0] - c.connect_radius;
+    for (int j = 1; j < n; ++j) {
+      const float v = s_md[j] - c.connect_radius;
+      w = (w != w || v != v) ? __builtin_nanf("") : fmaxf(w, v);
+    }
+    float c2 = (w <= 0.0f) ? w - 0.5f : w + 0.5f;
+    a.cost[((size_t)b * n + tid) * 3 + 2] = clampf_nan(c2, -1.0f, 1.0f);
+  }
   if (do_dyn && tid == 0) {
     float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    for (int g = 0; g < ng; ++g) s1 = (g == 0) ? s_d2g[0] : s1 + s_d2g[g];
-    for (int g = 0; g < ng; ++g) {
+    for (int g = 0; g < nrg; ++g) s1 = (g == 0) ? s_d2g[0] : s1 + s_d2g[g];
+    for (int g = 0; g < nrg; ++g) {
       float ind = (s_d2g[g] > c.dist2goal) ? 1.0f : 0.0f;
       s2 = (g == 0) ? ind : s2 + ind;
     }
     for (int i = 0; i < n; ++i) s3 = (i == 0) ? s_an2[0] : s3 + s_an2[i];
     float r = 0.0f;
-    r = r - (s1 / (float)ng) * 0.01f;
-    r = r - (s2 / (float)ng) * 0.001f;
+    r = r - (s1 / (float)nrg) * 0.01f;
+    r = r - (s2 / (float)nrg) * 0.001f;
     r = r - (s3 / (float)n) * 0.0001f;
     a.reward[b] = r;
   }
@@ -354,7 +387,7 @@ __global__ void env_step_kernel(StepArgs a) {
           const float* xo = s_obst + m * SD;
           f = make_float4(xi[0] - xo[0], xi[1] - xo[1], xi[2] - xo[2], xi[3] - xo[3]);
           float dx = xi[0] - xo[0], dy = xi[1] - xo[1];
-          mask = sqrtf(dx * dx + dy * dy) < c.comm_radius;
+          mask = sqrtf(dx * dx + dy * dy) < c.obs_mask_radius;    // comm_radius, or 100 x for Corridor / ConnectSpread
           sender = n + ng + m;
         }
       }
@@ -763,8 +796,8 @@ static size_t step_smem_bytes(const dgppo_env_cfg& c) {
   const bool lidar = cfg_is_lidar(c);
   const int kk = lidar ? (no > 0 ? c.top_k : 0) : 0;
   size_t fl = (lidar ? (size_t)no * 16 : 0) + (size_t)n * SD * 2 + (size_t)ng * SD + n * 2 + (size_t)no * cfg_obst_stride(c) + (size_t)n * kk * 4 +
-              (lidar ? (size_t)n * c.n_rays : 0) + n * 4 + ng * 4 + ng + n + n + (size_t)n * no + (size_t)n * n +
-              (size_t)n * (kk > no ? kk : no) + (size_t)ng * n;
+              (lidar ? (size_t)n * c.n_rays : 0) + n * 4 + ng * 4 + 3 * (size_t)cfg_reward_goals(c) + 3 * n + (size_t)n * no +
+              (size_t)n * n + (size_t)n * (kk > no ? kk : no) + (size_t)cfg_reward_goals(c) * n;
   return fl * sizeof(float);
 }
 
@@ -834,7 +867,8 @@ static int32_t launch_step(const dgppo_env_cfg* cfg, int mode, const float* agen
   const size_t fsmem = lidar ? lidar_smem_bytes(*cfg) : 0;
   if (launch_lidar_wave(a, s)) {
     // wave-per-env kernel for the benchmark topologies (env_wave.hip; same outputs bit for bit)
-  } else if (lidar && cfg->n_obs > 0 && cfg->n_rays == 32 && fsmem <= 60 * 1024 && !getenv("DGPPO_GENERIC_ENV_KERNEL")) {
+  } else if (lidar && cfg_is_base_kind(*cfg) && cfg->n_obs > 0 && cfg->n_rays == 32 && fsmem <= 60 * 1024 &&
+             !getenv("DGPPO_GENERIC_ENV_KERNEL")) {
     // specialised LiDAR kernel (same outputs bit for bit; see its header)
     const bool spread = cfg_is_spread(*cfg);
     const char* nt_env = getenv("DGPPO_ENV_BLOCK");

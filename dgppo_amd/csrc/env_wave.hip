@@ -734,7 +734,7 @@ extern "C" int32_t dgppo_debug_wave_spans(unsigned long long* out) {
 
 bool launch_lidar_wave(const StepArgs& a, hipStream_t s) {
   const dgppo_env_cfg& c = a.cfg;
-  if (!cfg_is_lidar(c) || c.n_rays != 32 || c.top_k != 8 || c.n_obs < 1) return false;
+  if (!cfg_is_lidar(c) || !cfg_is_base_kind(c) || c.n_rays != 32 || c.top_k != 8 || c.n_obs < 1) return false;
   if (getenv("DGPPO_NO_WAVE_ENV_KERNEL")) return false;
   if (!(c.eye_offset >= c.comm_radius)) return false;          // the diagonal of the agent-agent block must be masked
   // 16-byte staging loads need 16-byte aligned bases (torch allocations are; sliced views may not be)

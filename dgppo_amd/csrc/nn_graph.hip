@@ -155,7 +155,7 @@ __global__ void graph_feats_kernel(FeatArgs a) {
         const float* xo = s_ob + m * SD;
         const float* xi = s_ag + i * SD;
         f = make_float4(__fsub_rn(xi[0], xo[0]), __fsub_rn(xi[1], xo[1]), __fsub_rn(xi[2], xo[2]), __fsub_rn(xi[3], xo[3]));
-        mask = dist_rn(__fsub_rn(xi[0], xo[0]), __fsub_rn(xi[1], xo[1])) < c.comm_radius;
+        mask = dist_rn(__fsub_rn(xi[0], xo[0]), __fsub_rn(xi[1], xo[1])) < c.obs_mask_radius;   // mpe_corridor.py:93: 100 x comm_radius
       }
     }
     reinterpret_cast<float4*>(a.efeat)[(size_t)g * n * S + idx] = f;

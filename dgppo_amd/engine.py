@@ -68,7 +68,7 @@ class RolloutData:
         self.log_pi_tm = z(T, B, n) if stochastic else None
         self.rnn_tm = z(T + 1, B, n, carry_dim)          # packed actor carry [h_0 | h_1 | ...] of the stacked cells
         self.reward_tm = z(T, B)
-        self.cost_tm = z(T, B, n, 2)
+        self.cost_tm = z(T, B, n, cfg.n_cost)
         self._env_major = False
 
     def finalize(self):
@@ -94,7 +94,7 @@ class RolloutData:
         # stored carry of step t: pre-step (rollout, trainer/utils.py:46-51) or post-step (test_rollout, :71-77)
         self.rnn_states = self._rnn_em[:, :self.T] if self.stochastic else self._rnn_em[:, 1:]
         self.rewards = tr("rewards", self.reward_tm)                  # [B, T]
-        self.costs = tr("costs", self.cost_tm)                        # [B, T, n, 2]
+        self.costs = tr("costs", self.cost_tm)                        # [B, T, n, n_cost]
         self._env_major = True
         return self
 
@@ -124,7 +124,7 @@ class Engine:
         self._side_streams = None
         self._ro_cache: Dict[tuple, dict] = {}
         self._upd_graph: dict = {}
-        self.n_cost = 2
+        self.n_cost = cfg.n_cost              # 2, or 3 with MPEConnectSpread's connectivity cost
         # ONE flat fp32 buffer [g_policy | g_Vl | g_Vh | scalars]: each network's gradient buffer is a
         # 16-byte-aligned slice of it and the loss/metric sums of the minibatch (stats rows 0..2) sit at its tail, so the
         # data-parallel update needs a single all-reduce per minibatch.  Row 3 of the stats (the per-iteration safe count)

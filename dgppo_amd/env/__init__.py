@@ -6,10 +6,10 @@ from .base import MultiAgentEnv
 from .envs import LidarEnvState, MPEEnvState, Rectangle          # re-exported: users import them from dgppo.env
 
 DEFAULT_MAX_STEP = 128
-_BUILT = ("MPETarget", "MPESpread", "LidarSpread", "LidarTarget", "LidarBicycleTarget")
-# registered by the reference, outside the scope of this build (SURVEY §2 rows 20-21, §8f rank 2)
-_REFERENCE_ONLY = ("MPELine", "MPEFormation", "MPECorridor", "MPEConnectSpread", "LidarLine", "VMASReverseTransport",
-                   "VMASWheel")
+_BUILT = ("MPETarget", "MPESpread", "MPELine", "MPEFormation", "MPECorridor", "MPEConnectSpread", "LidarSpread",
+          "LidarTarget", "LidarLine", "LidarBicycleTarget")
+# registered by the reference, outside the scope of this build (SURVEY §2 rows 20-21)
+_REFERENCE_ONLY = ("VMASReverseTransport", "VMASWheel")
 ENV = {name: getattr(_envs, name) for name in _BUILT}
 globals().update(ENV)                                              # `from dgppo.env import LidarSpread` keeps working
 

@@ -41,12 +41,16 @@ class MultiAgentEnv(ABC):
         self._area_size = self._params["default_area_size"] if area_size is None else area_size
         self._dt = dt
         self._max_step = max_step
-        self.num_goals = num_agents
         self._device = device
         p = self._params
         self.cfg = N.make_env_cfg(N.ENV_KINDS[self.KIND], num_agents, p["n_obs"], p.get("n_rays", 32), p.get("top_k_rays", 8),
-                                  self._area_size, dt, p["car_radius"], p["comm_radius"], p.get("obs_radius", 0.05),
-                                  p["dist2goal"])
+                                  self._area_size, dt, p["car_radius"], p["comm_radius"], p.get("obs_radius"),
+                                  p["dist2goal"], p.get("connect_radius", 0.45), p.get("corridor_width", 0.2))
+        self.num_goals = self.cfg.n_goals                       # goal NODES: n, 2 landmarks (Line) or 1 (Formation)
+        # what the kind fixes is written back, as the reference does (mpe_corridor.py:35-39, mpe_connect_spread.py:38-40)
+        p["n_obs"] = self.cfg.n_obs
+        if not self.cfg.is_lidar:
+            p["obs_radius"] = float(np.float32(self.cfg.obs_radius)) if "obs_radius" not in p else p["obs_radius"]
         self._ray = None
 
     # ---- reference attribute surface ----
@@ -72,11 +76,12 @@ class MultiAgentEnv(ABC):
 
     @property
     def n_cost(self) -> int:
-        return 2
+        return self.cfg.n_cost
 
     @property
     def cost_components(self) -> Tuple[str, ...]:
-        return "agent collisions", "obs collisions"
+        base = ("agent collisions", "obs collisions")
+        return base + ("connectivity",) if self.cfg.n_cost == 3 else base          # mpe_connect_spread.py:50-52
 
     @property
     def state_dim(self) -> int:
@@ -107,7 +112,7 @@ class MultiAgentEnv(ABC):
         if self.cfg.kind == 2:
             return (torch.tensor([0., 0., -1., -1., -0.5]), torch.tensor([a, a, 1., 1., 0.5]))
         v = 0.5 if self.cfg.is_lidar else 1.0
-        return torch.tensor([0., 0., -v, -v]), torch.tensor([a, a, v, v])
+        return torch.tensor([0., 0., -v, -v]), torch.tensor([a, float(self.cfg.y_limit), v, v])   # y: 2 a for Corridor / ConnectSpread
 
     def action_lim(self):
         return -torch.ones(2), torch.ones(2)
@@ -136,7 +141,7 @@ class MultiAgentEnv(ABC):
         B = int(seeds.shape[0])
         n, sd = cfg.n_agents, cfg.state_dim
         agent = torch.empty(B, n, sd, device=dev)
-        goal = torch.empty(B, n, sd, device=dev)
+        goal = torch.empty(B, cfg.n_goals, sd, device=dev)
         obst = torch.empty(B, cfg.n_obs, cfg.obst_stride, device=dev) if cfg.n_obs > 0 else None
         OE.env_reset(cfg, seeds, agent, goal, obst)
         hits, g = None, None
@@ -159,7 +164,7 @@ class MultiAgentEnv(ABC):
         nx = torch.empty_like(st.agent)
         nh = torch.empty_like(st.hits) if st.hits is not None else None
         rew = torch.empty(B, device=dev)
-        cost = torch.empty(B, n, 2, device=dev)
+        cost = torch.empty(B, n, cfg.n_cost, device=dev)
         g = OE.alloc_graph(cfg, B, dev) if want_graph else None
         rc, rs = self._rays()
         OE.env_step(cfg, st.agent, action.contiguous(), st.goal, st.obst, st.hits, rc, rs, nx, nh, rew, cost, g)

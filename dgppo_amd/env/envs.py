@@ -67,12 +67,13 @@ class _LidarEnv(MultiAgentEnv):
         n, k = self.num_agents, self.cfg.top_k
         es = graph.env_states
         states = graph.states
+        ng = self.cfg.n_goals
         agent = states[..., :n, :].reshape(1, n, self.state_dim).contiguous()
-        goal = states[..., n:2 * n, :].reshape(1, n, self.state_dim).contiguous()
+        goal = states[..., n:n + ng, :].reshape(1, ng, self.state_dim).contiguous()
         obst = hits = None
         if self.cfg.n_obs > 0:
             obst = _records_from_rect(es.obstacle).reshape(1, self.cfg.n_obs, 16).contiguous()
-            hits = states[..., 2 * n:2 * n + n * k, :2].reshape(1, n, k, 2).contiguous()
+            hits = states[..., n + ng:n + ng + n * k, :2].reshape(1, n, k, 2).contiguous()
         return BatchState(agent, goal, obst, hits)
 
 
@@ -102,15 +103,60 @@ class _MPE(MultiAgentEnv):
     def _state_of(self, graph: GraphsTuple) -> BatchState:
         n = self.num_agents
         states = graph.states
+        ng = self.cfg.n_goals
         agent = states[..., :n, :].reshape(1, n, 4).contiguous()
-        goal = states[..., n:2 * n, :].reshape(1, n, 4).contiguous()
-        obst = states[..., 2 * n:2 * n + self.cfg.n_obs, :].reshape(1, self.cfg.n_obs, 4).contiguous() if self.cfg.n_obs > 0 else None
+        goal = states[..., n:n + ng, :].reshape(1, ng, 4).contiguous()
+        obst = states[..., n + ng:n + ng + self.cfg.n_obs, :].reshape(1, self.cfg.n_obs, 4).contiguous() if self.cfg.n_obs > 0 else None
         return BatchState(agent, goal, obst, None)
 
 
 class MPESpread(_MPE):
     KIND = "MPESpread"
     PARAMS = dict(_MPE.PARAMS)
+
+
+# ---- task variants: same kernels; reset, reward goals and goal-node count differ ----------------------
+class LidarLine(_LidarEnv):
+    """dgppo/env/lidar_env/lidar_line.py: two landmark nodes; the n reward goals divide the segment between them."""
+    KIND = "LidarLine"
+    PARAMS = dict(_LidarEnv.PARAMS)
+
+    def landmark2goal(self, landmarks):
+        n = self.num_agents
+        return landmarks[..., 0:1, :] + torch.arange(n, device=landmarks.device, dtype=torch.float32)[:, None] * \
+            (landmarks[..., 1:2, :] - landmarks[..., 0:1, :]) / (n - 1)
+
+
+class MPELine(_MPE):
+    """dgppo/env/mpe/mpe_line.py (n <= 3: the goals are the interior division points, :126-128)."""
+    KIND = "MPELine"
+    PARAMS = dict(_MPE.PARAMS)
+
+    def landmark2goal(self, landmarks):
+        n = self.num_agents
+        idx, den = (torch.arange(1, n + 1), n + 1) if n <= 3 else (torch.arange(0, n), n - 1)
+        idx = idx.to(device=landmarks.device, dtype=torch.float32)
+        return landmarks[..., 0:1, :] + idx[:, None] * (landmarks[..., 1:2, :] - landmarks[..., 0:1, :]) / den
+
+
+class MPEFormation(_MPE):
+    """dgppo/env/mpe/mpe_formation.py: one landmark node; the reward goals lie on a circle of radius comm_radius."""
+    KIND = "MPEFormation"
+    PARAMS = dict(_MPE.PARAMS)
+
+
+class MPECorridor(_MPE):
+    """dgppo/env/mpe/mpe_corridor.py: two fixed discs leave a corridor; agents start below it, goals lie above."""
+    KIND = "MPECorridor"
+    PARAMS = {"car_radius": 0.05, "comm_radius": 0.5, "default_area_size": 1.0, "dist2goal": 0.01, "n_obs": 2,
+              "corridor_width": 0.2}
+
+
+class MPEConnectSpread(_MPE):
+    """dgppo/env/mpe/mpe_connect_spread.py: a third cost keeps the team connected while it passes one large disc."""
+    KIND = "MPEConnectSpread"
+    PARAMS = {"car_radius": 0.05, "comm_radius": 0.5, "default_area_size": 1.0, "dist2goal": 0.01, "n_obs": 1,
+              "obs_radius": 0.25, "connect_radius": 0.45}
 
 
 class MPETarget(_MPE):

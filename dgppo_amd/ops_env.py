@@ -76,7 +76,7 @@ def env_step(cfg: N.EnvCfg, agent, action, goal, obst, hits, ray_cos, ray_sin,
     if action is not None:
         N.expect_shape(action, (B, n, 2), "action")
         N.expect_shape(reward, (B,), "reward")
-        N.expect_shape(cost, (B, n, 2), "cost")
+        N.expect_shape(cost, (B, n, cfg.n_cost), "cost")
     if next_agent is not None:
         N.expect_shape(next_agent, (B, n, cfg.state_dim), "next_agent")
     if next_hits is not None:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGPPO_ABI_VERSION 2
+#define DGPPO_ABI_VERSION 3
 
 /* environment kinds — dgppo/env/__init__.py:9-23 (registered ids on the hot path) */
 enum {
@@ -36,7 +36,20 @@ enum {
   DGPPO_ENV_LIDAR_TARGET = 1,         /* dgppo/env/lidar_env/lidar_target.py */
   DGPPO_ENV_LIDAR_BICYCLE_TARGET = 2, /* dgppo/env/lidar_env/lidar_bicycle_target.py */
   DGPPO_ENV_MPE_SPREAD = 3,           /* dgppo/env/mpe/mpe_spread.py */
-  DGPPO_ENV_MPE_TARGET = 4            /* dgppo/env/mpe/mpe_target.py */
+  DGPPO_ENV_MPE_TARGET = 4,           /* dgppo/env/mpe/mpe_target.py */
+  /* task variants: same step / graph kernels, different reset, reward goals, goal-node count */
+  DGPPO_ENV_LIDAR_LINE = 5,           /* dgppo/env/lidar_env/lidar_line.py : 2 landmark nodes, goals on the segment */
+  DGPPO_ENV_MPE_LINE = 6,             /* dgppo/env/mpe/mpe_line.py */
+  DGPPO_ENV_MPE_FORMATION = 7,        /* dgppo/env/mpe/mpe_formation.py : 1 landmark node, goals on a circle */
+  DGPPO_ENV_MPE_CORRIDOR = 8,         /* dgppo/env/mpe/mpe_corridor.py : two fixed discs, y limit 2 * area */
+  DGPPO_ENV_MPE_CONNECT_SPREAD = 9    /* dgppo/env/mpe/mpe_connect_spread.py : third (connectivity) cost */
+};
+/* dgppo_env_cfg.reward_goals: how the n positions the reward measures against follow from the goal nodes */
+enum {
+  DGPPO_GOALS_NODES = 0,         /* the goal nodes themselves                                   lidar_spread.py:35-52   */
+  DGPPO_GOALS_LINE = 1,          /* l0 + i (l1 - l0) / (n - 1), i = 0..n-1                      lidar_line.py:131-136   */
+  DGPPO_GOALS_LINE_INTERIOR = 2, /* l0 + (i + 1) (l1 - l0) / (n + 1)  (MPELine, n <= 3)         mpe_line.py:124-133     */
+  DGPPO_GOALS_CIRCLE = 3         /* landmark + comm_radius [cos, sin](2 pi i / n)               mpe_formation.py:94-98  */
 };
 
 /* Obstacle record of the LiDAR envs: 16 floats per rectangle
@@ -53,7 +66,7 @@ enum {
 typedef struct dgppo_env_cfg {
   int32_t kind;        /* DGPPO_ENV_* */
   int32_t n_agents;    /* n */
-  int32_t n_goals;     /* = n */
+  int32_t n_goals;     /* goal NODES of the graph: n, 2 (Line: landmarks) or 1 (Formation) */
   int32_t n_obs;       /* rectangles (LiDAR) or discs (MPE); may be 0 */
   int32_t n_rays;      /* R (LiDAR only) */
   int32_t top_k;       /* k = top_k_rays (LiDAR only) */
@@ -70,7 +83,16 @@ typedef struct dgppo_env_cfg {
   float eye_offset;        /* fp32(comm_radius + 1)                      lidar_spread.py:64   */
   float car_plus_obs;      /* fp32(car_radius + obs_radius)              mpe/base.py:181      */
   float vel_limit;         /* 0.5 (LiDAR) or 1.0 (MPE)                   state_lim()          */
-  float reset_min_dist;    /* fp32(2.2*car_radius) LiDAR, fp32(2*car_radius) MPE              */
+  float reset_min_dist;    /* fp32(2.2*car_radius) LiDAR, fp32(2*car_radius) MPE, fp32(2.3*car_radius) ConnectSpread */
+  /* ---- task variants (ABI 3); defaults reproduce the five base kinds ---- */
+  int32_t reward_goals;    /* DGPPO_GOALS_*                                                                          */
+  int32_t n_cost;          /* 2, or 3 with the connectivity cost                   mpe_connect_spread.py:46-52,115-117 */
+  float obs_mask_radius;   /* MPE agent-obstacle edge mask: comm_radius, or fp32(100*comm_radius)  mpe_corridor.py:93   */
+  float y_limit;           /* upper state limit in y: area_size or fp32(2*area_size)               mpe_corridor.py:62-65 */
+  float connect_radius;    /* mpe_connect_spread.py:24                                                                */
+  float reset_side_y;      /* height of the box agents / goals are sampled in at reset             mpe_corridor.py:50   */
+  float goal_shift_y;      /* added to the sampled goals' y                                        mpe_corridor.py:52   */
+  float line_min_dist;     /* minimum landmark separation                                          mpe_line.py:49-52    */
 } dgppo_env_cfg;
 
 /* Optional materialised GraphsTuple (dgppo/utils/graph.py:47-86, GetGraph.to_padded

@@ -20,10 +20,17 @@ import numpy as np
 f32 = np.float32
 
 LIDAR_SPREAD, LIDAR_TARGET, LIDAR_BICYCLE_TARGET, MPE_SPREAD, MPE_TARGET = range(5)
+# task variants: lidar_env/lidar_line.py, mpe/mpe_line.py, mpe_formation.py, mpe_corridor.py, mpe_connect_spread.py
+LIDAR_LINE, MPE_LINE, MPE_FORMATION, MPE_CORRIDOR, MPE_CONNECT_SPREAD = range(5, 10)
 KIND_NAMES = {
     "LidarSpread": LIDAR_SPREAD, "LidarTarget": LIDAR_TARGET, "LidarBicycleTarget": LIDAR_BICYCLE_TARGET,
-    "MPESpread": MPE_SPREAD, "MPETarget": MPE_TARGET,
+    "MPESpread": MPE_SPREAD, "MPETarget": MPE_TARGET, "LidarLine": LIDAR_LINE, "MPELine": MPE_LINE,
+    "MPEFormation": MPE_FORMATION, "MPECorridor": MPE_CORRIDOR, "MPEConnectSpread": MPE_CONNECT_SPREAD,
 }
+# how the n reward goals follow from the goal nodes (landmarks): the nodes themselves; n points on the segment between two
+# landmarks, ends included (lidar_line.py:131-136, mpe_line.py:124-133 for n > 3); n interior points (mpe_line.py n <= 3);
+# n points on a circle of radius comm_radius around one landmark (mpe_formation.py:94-98)
+GOALS_NODES, GOALS_LINE, GOALS_LINE_INTERIOR, GOALS_CIRCLE = range(4)
 RECT_STRIDE = 16
 
 
@@ -43,13 +50,29 @@ class EnvCfg:
     obs_radius: float = 0.05
     dist2goal: float = 0.01
 
+    connect_radius: float = 0.45          # MPEConnectSpread (mpe_connect_spread.py:24)
+    corridor_width: float = 0.2           # MPECorridor (mpe_corridor.py:19)
+
+    def __post_init__(self):
+        # PARAMS the variants override (make_env passes area_size=None: the class default applies)
+        if self.kind in (MPE_CORRIDOR, MPE_CONNECT_SPREAD) and self.area_size == 1.5:
+            self.area_size = 1.0                                     # default_area_size of both
+        if self.kind == MPE_CORRIDOR:
+            self.n_obs = 2                                           # mpe_corridor.py:35-37
+            self.obs_radius = (self.area_size - self.corridor_width) / 4   # :39
+        if self.kind == MPE_CONNECT_SPREAD:
+            self.n_obs = 1                                           # mpe_connect_spread.py:38-40
+            if self.obs_radius == 0.05:
+                self.obs_radius = 0.25
+
     @property
     def is_lidar(self):
-        return self.kind in (LIDAR_SPREAD, LIDAR_TARGET, LIDAR_BICYCLE_TARGET)
+        return self.kind in (LIDAR_SPREAD, LIDAR_TARGET, LIDAR_BICYCLE_TARGET, LIDAR_LINE)
 
     @property
     def is_spread(self):
-        return self.kind in (LIDAR_SPREAD, MPE_SPREAD)
+        """every agent is connected to every goal node (lidar_spread.py:70-76, mpe_spread.py:63-69 and their subclasses)"""
+        return self.kind not in (LIDAR_TARGET, LIDAR_BICYCLE_TARGET, MPE_TARGET)
 
     @property
     def is_bicycle(self):
@@ -57,7 +80,35 @@ class EnvCfg:
 
     @property
     def n_goals(self):
+        if self.kind in (LIDAR_LINE, MPE_LINE):
+            return 2
+        if self.kind == MPE_FORMATION:
+            return 1
         return self.n_agents
+
+    @property
+    def reward_goals(self):
+        if self.kind == LIDAR_LINE:
+            return GOALS_LINE
+        if self.kind == MPE_LINE:
+            return GOALS_LINE if self.n_agents > 3 else GOALS_LINE_INTERIOR
+        if self.kind == MPE_FORMATION:
+            return GOALS_CIRCLE
+        return GOALS_NODES
+
+    @property
+    def n_cost(self):
+        return 3 if self.kind == MPE_CONNECT_SPREAD else 2
+
+    @property
+    def obs_mask_radius(self):
+        """MPE agent-obstacle edges: within comm_radius, or always connected (mpe_corridor.py:93, mpe_connect_spread.py:169)"""
+        return self.comm_radius * 100 if self.kind in (MPE_CORRIDOR, MPE_CONNECT_SPREAD) else self.comm_radius
+
+    @property
+    def y_limit(self):
+        """upper state limit in y (mpe_corridor.py:62-65, mpe_connect_spread.py:140-143)"""
+        return self.area_size * 2 if self.kind in (MPE_CORRIDOR, MPE_CONNECT_SPREAD) else self.area_size
 
     @property
     def state_dim(self):
@@ -188,7 +239,7 @@ def state_limits(cfg: EnvCfg):
     else:
         v = f32(cfg.vel_limit)
         lo = np.array([0, 0, -v, -v], f32)
-        hi = np.array([a, a, v, v], f32)
+        hi = np.array([a, f32(cfg.y_limit), v, v], f32)
     return lo, hi
 
 
@@ -281,9 +332,33 @@ def lidar_sense(cfg: EnvCfg, pos, obst, ray_cos, ray_sin):
 # --------------------------------------------------------------------------------------------------
 # reward / cost   (lidar_spread.py:35-52, lidar_target.py:35-52, mpe twins ; lidar_env/base.py:180-207, mpe/base.py:164-191)
 # --------------------------------------------------------------------------------------------------
+def reward_goal_positions(cfg: EnvCfg, goal):
+    """[B, n_goals, >=2] goal nodes -> [B, n_reward_goals, 2] positions the reward measures against."""
+    gp = goal[..., :2].astype(f32)
+    mode, n = cfg.reward_goals, cfg.n_agents
+    if mode == GOALS_NODES:
+        return gp
+    if mode in (GOALS_LINE, GOALS_LINE_INTERIOR):
+        # landmark2goal: goals = l0 + arange(...)[:, None] * (l1 - l0) / n_interval, evaluated left to right in fp32
+        direction = (gp[:, 1] - gp[:, 0]).astype(f32)                                    # [B,2]
+        if mode == GOALS_LINE:
+            idx, n_interval = np.arange(0, n, dtype=f32), f32(n - 1)
+        else:
+            idx, n_interval = np.arange(1, n + 1, dtype=f32), f32(n + 1)
+        step = ((idx[None, :, None] * direction[:, None, :]).astype(f32) / n_interval).astype(f32)
+        return (gp[:, 0][:, None, :] + step).astype(f32)
+    # GOALS_CIRCLE: thetas = linspace(0, 2 pi, n + 1)[:-1]  [upstream: jnp.linspace = start + (iota / div) * delta],
+    # goals = landmark + R * [cos, sin]
+    t = (np.arange(n, dtype=f32) / f32(n)).astype(f32)
+    th = (t * f32(2 * np.pi)).astype(f32)
+    R = f32(cfg.comm_radius)
+    off = np.stack([(R * np.cos(th).astype(f32)).astype(f32), (R * np.sin(th).astype(f32)).astype(f32)], axis=-1)
+    return (gp[:, 0][:, None, :] + off[None]).astype(f32)
+
+
 def get_reward(cfg: EnvCfg, agent, goal, action):
     ap = agent[..., :2]
-    gp = goal[..., :2]
+    gp = reward_goal_positions(cfg, goal)
     n = cfg.n_agents
     if cfg.is_spread:
         d = norm2(gp[:, :, None, 0] - ap[:, None, :, 0], gp[:, :, None, 1] - ap[:, None, :, 1])   # [B,g,j]
@@ -318,9 +393,19 @@ def get_cost(cfg: EnvCfg, agent, hits_or_obs):
         op = hits_or_obs[..., :2]                                              # [B,n_obs,2]
         dd = norm2(ap[:, :, None, 0] - op[:, None, :, 0], ap[:, :, None, 1] - op[:, None, :, 1])
         obs_cost = (f32(cfg.car_radius + cfg.obs_radius) - nan_min(dd, 2)).astype(f32)
-    cost = np.stack([agent_cost, obs_cost], axis=-1)
+    comps = [agent_cost, obs_cost]
+    if cfg.n_cost == 3:
+        # connectivity (mpe_connect_spread.py:115-117): the largest nearest-neighbour distance against connect_radius, the
+        # same value for every agent
+        with np.errstate(invalid="ignore"):
+            worst = (min_dist - f32(cfg.connect_radius)).astype(f32)
+        cc = worst[:, 0].copy()
+        for j in range(1, n):                                        # jnp.max: NaN propagates
+            cc = np.where(np.isnan(cc) | np.isnan(worst[:, j]), f32(np.nan), np.maximum(cc, worst[:, j])).astype(f32)
+        comps.append(np.broadcast_to(cc[:, None], (B, n)).astype(f32))
+    cost = np.stack(comps, axis=-1)
     cost = np.where(cost <= 0.0, (cost - f32(0.5)).astype(f32), (cost + f32(0.5)).astype(f32)).astype(f32)
-    if cfg.is_lidar:
+    if cfg.is_lidar or cfg.kind == MPE_CONNECT_SPREAD:               # mpe_connect_spread.py:134 clips both sides
         cost = np.minimum(np.maximum(cost, f32(-1.0)), f32(1.0))
     else:
         cost = np.maximum(cost, f32(-1.0))            # mpe/base.py:189 clips only from below
@@ -403,7 +488,7 @@ def get_graph(cfg: EnvCfg, agent, goal, obst, hits):
     elif cfg.n_obs > 0:       # MPETarget with n_obs == 0 is guarded like MPESpread (mpe_spread.py:71-72)
         op = obst[..., :2]
         dd = norm2(ap[:, :, None, 0] - op[:, None, :, 0], ap[:, :, None, 1] - op[:, None, :, 1])
-        ao_mask = dd < f32(cfg.comm_radius)
+        ao_mask = dd < f32(cfg.obs_mask_radius)
         ao_feats = (agent[:, :, None, :4] - obst[:, None, :, :4]).astype(f32)
         blocks.append(_edge_block(ao_feats, ao_mask, id_agent, np.arange(cfg.n_obs) + n + ng, pad_id))
     edges = np.concatenate([b[0] for b in blocks], axis=1)
@@ -468,8 +553,172 @@ class _Stream:
         return u01(w[0]), u01(w[1])
 
 
+def reset_thresholds(cfg: EnvCfg):
+    """thresholds of the variant resets, formed in Python doubles and rounded once to fp32 (as the reference's weakly typed
+    Python floats are); the same numbers travel to the device in dgppo_env_cfg."""
+    cr, A = cfg.car_radius, cfg.area_size
+    d = dict(min_dist=2 * cr, side_y=A, goal_shift_y=0.0, line_min_dist=0.0)
+    if cfg.kind in (MPE_CORRIDOR, MPE_CONNECT_SPREAD):
+        d["side_y"] = (A - cfg.obs_radius * 2) / 2 - 1.5 * cr                    # mpe_corridor.py:50, mpe_connect_spread.py:79
+        d["goal_shift_y"] = A - (A - cfg.obs_radius * 2) / 2 + 1.5 * cr          # :52, :81-83
+    if cfg.kind == MPE_CONNECT_SPREAD:
+        d["min_dist"] = 2.3 * cr                                                 # :77
+    if cfg.kind in (LIDAR_LINE, MPE_LINE):
+        n = cfg.n_agents
+        d["line_min_dist"] = n * 5 * cr if (cfg.kind == MPE_LINE and n <= 3) else (n - 2) * 6 * cr   # mpe_line.py:49-52
+    return {k: f32(v) for k, v in d.items()}
+
+
+def _sample_pairs(st, n, Ax, Ay, min_dist, max_iter=1024):
+    """get_node_goal_rng (env/utils.py:139-244) without obstacles: agents and goals alternately, each at least min_dist from
+    the rows already placed (zero rows of the work arrays included), <= max_iter tries each, restart on failure."""
+    while True:
+        states = np.zeros((n, 2), f32)
+        goals = np.zeros((n, 2), f32)
+        failed = False
+        for i in range(n):
+            its = []
+            for arr in (states, goals):
+                it = 0
+                while True:
+                    u0, u1 = st.uniform2()
+                    cand = np.array([u0 * Ax, u1 * Ay], f32)
+                    dmin = np.min(norm2(arr[:, 0] - cand[0], arr[:, 1] - cand[1]))
+                    if (not (dmin <= min_dist)) or it >= max_iter:
+                        break
+                    it += 1
+                arr[i] = cand
+                its.append(it)
+            if max(its) >= max_iter:
+                failed = True
+                break
+        if not failed:
+            return states, goals
+
+
+def _nn_dist(p):
+    d = norm2(p[:, None, 0] - p[None, :, 0], p[:, None, 1] - p[None, :, 1])
+    d = (d + (np.eye(len(p), dtype=f32) * f32(1e6)).astype(f32)).astype(f32)
+    return d.min(axis=1)
+
+
+def _reset_variant(cfg: EnvCfg, seed: int):
+    """lidar_line.py:39-129, mpe_line.py:36-122, mpe_formation.py:37-92, mpe_corridor.py:41-60, mpe_connect_spread.py:50-107.
+    Stream: the same Philox draws as env_reset_single, consumed in the order of the statements below.  Deviation: the
+    landmark's quarter-turn (region * pi / 2) uses exact rotations instead of fp32 cos / sin of k * pi / 2 (4e-8 off)."""
+    st = _Stream(int(seed))
+    n, sd, A = cfg.n_agents, cfg.state_dim, f32(cfg.area_size)
+    th = reset_thresholds(cfg)
+    cr = f32(cfg.car_radius)
+    obst = None
+    if cfg.kind == MPE_CONNECT_SPREAD:
+        for attempt in range(4096):                     # the reference loops without bound (n == 1 would never end)
+            states, goals = _sample_pairs(st, n, A, th["side_y"], th["min_dist"])
+            mda, mdg = _nn_dist(states), _nn_dist(goals)
+            bad = bool(np.any(mda > f32(cfg.connect_radius))) or bool(np.any(mda < f32(2 * cfg.car_radius))) \
+                or bool(np.any(mdg > f32(cfg.connect_radius)))
+            if not bad:
+                break
+        goals = goals.copy()
+        goals[:, 1] = (goals[:, 1] + th["goal_shift_y"]).astype(f32)
+        u0, _ = st.uniform2()
+        r_o = f32(cfg.obs_radius)
+        ox = f32(r_o + f32(u0 * f32(f32(A - r_o) - r_o)))
+        obst = np.zeros((1, sd), f32)
+        obst[0, :2] = [ox, f32(A / f32(2))]
+        goal_nodes = goals
+    elif cfg.kind == MPE_CORRIDOR:
+        states, goals = _sample_pairs(st, n, A, th["side_y"], th["min_dist"])
+        goals = goals.copy()
+        goals[:, 1] = (goals[:, 1] + th["goal_shift_y"]).astype(f32)
+        r_o = f32(cfg.obs_radius)
+        obst = np.zeros((2, sd), f32)
+        obst[0, :2] = [r_o, f32(A / f32(2))]
+        obst[1, :2] = [f32(A - r_o), f32(A / f32(2))]
+        goal_nodes = goals
+    else:
+        states, _ = _sample_pairs(st, n, A, A, th["min_dist"])
+        if cfg.kind == MPE_FORMATION:
+            # formed in double from the fp32 PARAMS, rounded once (the host side of dgppo_env_reset does the same)
+            d = lambda v: float(f32(v))
+            lo = f32(d(cfg.comm_radius) + 2.0 * d(cfg.car_radius))
+            hi = f32(d(cfg.area_size) - d(cfg.comm_radius) - 2.0 * d(cfg.car_radius))
+            u0, u1 = st.uniform2()
+            landmarks = np.array([[f32(lo + f32(u0 * f32(hi - lo))), f32(lo + f32(u1 * f32(hi - lo)))]], f32)
+        else:
+            md = th["line_min_dist"]
+            if cfg.kind == MPE_LINE and n <= 3:
+                u0, u1 = st.uniform2()
+                l0 = np.array([u0 * A, u1 * A], f32)
+            else:
+                side = f32(A - md)
+                assert side >= 0, "The area size is too small to place the landmarks."
+                u0, u1 = st.uniform2()
+                cx = f32(f32(u0 * f32(A - side)) - f32(A / f32(2)))
+                cy = f32(f32(u1 * side) + f32(f32(A / f32(2)) - side))
+                u0, _ = st.uniform2()
+                region = min(int(f32(u0 * f32(4.0))), 3)
+                rx, ry = [(cx, cy), (f32(-cy), cx), (f32(-cx), f32(-cy)), (cy, f32(-cx))][region]
+                l0 = np.array([f32(rx + f32(A / f32(2))), f32(ry + f32(A / f32(2)))], f32)
+            while True:
+                u0, u1 = st.uniform2()
+                l1 = np.array([u0 * A, u1 * A], f32)
+                if not (norm2(l1[0] - l0[0], l1[1] - l0[1]) < md):
+                    break
+            landmarks = np.stack([l0, l1]).astype(f32)
+        goal_nodes = landmarks
+        rgoals = reward_goal_positions(cfg, landmarks[None])[0]
+        if cfg.is_lidar:
+            # lidar_line.py:88-118: rectangles that keep 1.1 car radii from every agent and every line goal
+            obst = np.zeros((cfg.n_obs, RECT_STRIDE), f32)
+            pts = np.concatenate([states, rgoals], 0)
+            r_in = f32(float(f32(cfg.car_radius)) * 1.1)
+            for o in range(cfg.n_obs):
+                while True:
+                    u0, u1 = st.uniform2()
+                    cx, cy = f32(u0 * A), f32(u1 * A)
+                    u0, u1 = st.uniform2()
+                    lo, hi = f32(0.1), f32(0.3)
+                    w = f32(lo + f32(u0 * f32(hi - lo)))
+                    h = f32(lo + f32(u1 * f32(hi - lo)))
+                    u0, _ = st.uniform2()
+                    rec = make_rect(np.array([cx, cy], f32), w, h, f32(u0 * f32(np.pi)))
+                    if not bool(np.any(rect_inside(pts[:, 0], pts[:, 1], rec[None], r_in))):
+                        break
+                obst[o] = rec
+        else:
+            # mpe_line.py:88-112 / mpe_formation.py:55-79: discs, rejection vs agents / reward goals / border
+            obst = np.zeros((cfg.n_obs, sd), f32)
+            lo = f32(cr * f32(3.0))
+            hi = f32(A - lo)
+            thr_a = f32(cfg.car_radius + cfg.obs_radius)
+            thr_g = f32(f32(cfg.car_radius * 2) + f32(cfg.obs_radius))
+            for o in range(cfg.n_obs):
+                first = True
+                while True:
+                    u0, u1 = st.uniform2()
+                    if first:
+                        cand = np.array([u0 * A, u1 * A], f32)
+                        first = False
+                    else:
+                        cand = np.array([lo + u0 * f32(hi - lo), lo + u1 * f32(hi - lo)], f32)
+                    da = np.min(norm2(states[:, 0] - cand[0], states[:, 1] - cand[1]))
+                    dg = np.min(norm2(rgoals[:, 0] - cand[0], rgoals[:, 1] - cand[1]))
+                    bad = (da <= thr_a) or (dg <= thr_g) or bool(np.any(cand < lo)) or bool(np.any(cand > hi))
+                    if not bad:
+                        break
+                obst[o, :2] = cand
+    agent = np.zeros((n, sd), f32)
+    goal = np.zeros((cfg.n_goals, sd), f32)
+    agent[:, :2] = states
+    goal[:, :2] = goal_nodes
+    return agent, goal, obst
+
+
 def env_reset_single(cfg: EnvCfg, seed: int):
-    """one env; pure-Python loops (small cases only).  Returns agent [n,sd], goal [n,sd], obst."""
+    """one env; pure-Python loops (small cases only).  Returns agent [n,sd], goal [n_goals,sd], obst."""
+    if cfg.kind >= LIDAR_LINE:
+        return _reset_variant(cfg, seed)
     st = _Stream(int(seed))
     n, sd = cfg.n_agents, cfg.state_dim
     A = f32(cfg.area_size)

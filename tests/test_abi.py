@@ -1,6 +1,8 @@
 """CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/*.h declares,
 and argument validation fails loudly without touching a GPU."""
 import ctypes as C
+
+import numpy as np
 import glob
 import os
 import re
@@ -38,7 +40,7 @@ def test_library_loads_and_exports_all_declared_symbols():
 
 def test_cfg_struct_matches_header_and_sizes():
     from dgppo_amd import _native as N
-    assert C.sizeof(N.EnvCfg) == 8 * 4 + 12 * 4
+    assert C.sizeof(N.EnvCfg) == 8 * 4 + 12 * 4 + 8 * 4          # ABI 3: + the eight task-variant fields
     cfg = N.make_env_cfg(0, 8, 3)
     lib = N.lib()
     lib.dgppo_env_num_nodes.restype = C.c_int32
@@ -49,6 +51,17 @@ def test_cfg_struct_matches_header_and_sizes():
     assert lib.dgppo_env_num_nodes(C.byref(cfg5)) == 161 and lib.dgppo_env_num_edges(C.byref(cfg5)) == 400
     cfg2 = N.make_env_cfg(3, 3, 3)
     assert lib.dgppo_env_num_nodes(C.byref(cfg2)) == 10 and lib.dgppo_env_num_edges(C.byref(cfg2)) == 27
+    # task variants: 2 landmark nodes (Line), 1 (Formation), fixed obstacle counts (Corridor 2, ConnectSpread 1)
+    for kind, n, n_obs, nodes, edges in ((5, 4, 3, 4 + 2 + 32 + 1, 4 * (4 + 2 + 8)), (6, 5, 2, 5 + 2 + 2 + 1, 5 * (5 + 2 + 2)),
+                                         (7, 4, 3, 4 + 1 + 3 + 1, 4 * (4 + 1 + 3)), (8, 4, 5, 4 + 4 + 2 + 1, 4 * (4 + 4 + 2)),
+                                         (9, 4, 0, 4 + 4 + 1 + 1, 4 * (4 + 4 + 1))):
+        cv = N.make_env_cfg(kind, n, n_obs)
+        assert lib.dgppo_env_num_nodes(C.byref(cv)) == nodes == cv.num_nodes, (kind, lib.dgppo_last_error())
+        assert lib.dgppo_env_num_edges(C.byref(cv)) == edges == cv.num_edges
+    assert N.make_env_cfg(9, 4, 0).n_cost == 3 and N.make_env_cfg(8, 4, 0).obs_radius == np.float32((1.0 - 0.2) / 4)
+    bad = N.make_env_cfg(6, 5, 2)
+    bad.n_goals = 5                                               # MPELine must carry its 2 landmarks
+    assert lib.dgppo_env_num_nodes(C.byref(bad)) == -1
     cfg1 = N.make_env_cfg(4, 3, 0)
     assert lib.dgppo_env_num_nodes(C.byref(cfg1)) == 7 and lib.dgppo_env_num_edges(C.byref(cfg1)) == 12
 

@@ -54,7 +54,7 @@ def _run_step(cfg, ocfg, agent, goal, obst, hits, action, dev, want_graph=True):
     nx = torch.empty(B, n, cfg.state_dim, device=dev)
     nh = torch.empty(B, n, cfg.top_k, 2, device=dev) if (cfg.is_lidar and cfg.n_obs > 0) else None
     rew = torch.empty(B, device=dev)
-    cost = torch.empty(B, n, 2, device=dev)
+    cost = torch.empty(B, n, cfg.n_cost, device=dev)
     g = O.alloc_graph(cfg, B, dev) if want_graph else None
     O.env_step(cfg, _to(agent, dev), _to(action, dev), _to(goal, dev), _to(obst, dev), _to(hits, dev), rc, rs,
                nx, nh, rew if action is not None else None, cost if action is not None else None, g)
@@ -313,3 +313,71 @@ def test_wave_kernel_equals_workgroup_kernel_and_oracle(cuda, monkeypatch, kind,
         p = want["next_agent"][0, 0, :2]
         assert np.all(want["next_hits"][0, 0] == p), "agent inside an obstacle: all hit points collapse onto the agent"
         assert (np.abs(want["next_hits"]) > 1e5).any()
+
+
+# ---- task variants -------------------------------------------------------------------------------------
+VARIANTS = [("LidarLine", 4, 3), ("LidarLine", 6, 2), ("MPELine", 3, 3), ("MPELine", 5, 2), ("MPEFormation", 4, 3),
+            ("MPECorridor", 4, 2), ("MPEConnectSpread", 4, 1), ("MPEConnectSpread", 6, 1)]
+
+
+@pytest.mark.parametrize("kind,n,n_obs", VARIANTS)
+def test_variant_step_matches_oracle(cuda, kind, n, n_obs):
+    """LidarLine / MPELine (2 landmark nodes, goals on the segment), MPEFormation (1 landmark, goals on a circle), MPECorridor
+    (obstacle edges always connected, y limit 2 A), MPEConnectSpread (third cost, clipped on both sides): the generic step
+    kernel against the oracle — everything bit-exact except MPEFormation's reward (device cosf / sinf: 1e-6)."""
+    cfg, ocfg = _mk(kind, n, n_obs)
+    assert (cfg.n_goals, cfg.n_cost, cfg.n_obs) == (ocfg.n_goals, ocfg.n_cost, ocfg.n_obs)
+    B = 48
+    agent, goal, obst, action = _random_state(ocfg, B, seed=17 + n)
+    if kind in ("MPECorridor", "MPEConnectSpread"):
+        agent[::3, :, 1] += f32(0.9)                                  # some agents beyond y = area: only legal with y_limit = 2 A
+        agent[::3, :, 3] = f32(1.0)
+        agent[1::3, 0, :2] = f32(0.01)                                # one straggler: the team is disconnected in these envs
+    tab = E.ray_table(32)
+    hits = E.lidar_sense(ocfg, agent[..., :2], obst, *tab)[0] if ocfg.is_lidar else None
+    want = E.env_step(ocfg, agent, goal, obst, hits, action, tab)
+    got = _run_step(cfg, ocfg, agent, goal, obst, hits, action, cuda)
+    np.testing.assert_array_equal(got["next_agent"].view(np.uint32), want["next_agent"].view(np.uint32))
+    np.testing.assert_array_equal(got["cost"].view(np.uint32), want["cost"].view(np.uint32))
+    assert got["cost"].shape == (B, n, ocfg.n_cost)
+    if kind == "MPEFormation":
+        np.testing.assert_allclose(got["reward"], want["reward"], atol=1e-7, rtol=1e-6)
+    else:
+        np.testing.assert_array_equal(got["reward"].view(np.uint32), want["reward"].view(np.uint32))
+    if want["next_hits"] is not None:
+        np.testing.assert_array_equal(got["next_hits"].view(np.uint32), want["next_hits"].view(np.uint32))
+    _assert_graph_equal(got["graph"], want["graph"])
+    assert got["graph"]["nodes"].shape == (B, ocfg.num_nodes, ocfg.node_dim)
+    if kind in ("MPECorridor", "MPEConnectSpread"):
+        assert (got["next_agent"][..., 1] > ocfg.area_size).any(), "the 2 A y-limit was never exercised"
+        pad = ocfg.num_nodes - 1
+        obs_block = want["graph"]["senders"][:, n * n + n * ocfg.n_goals:]
+        assert (obs_block != pad).all(), "agent-obstacle edges are always connected in these two tasks"
+    if kind == "MPEConnectSpread":
+        c2 = got["cost"][..., 2]
+        assert (c2 == c2[:, :1]).all() and (c2 > 0).any() and (c2 < 0).any()      # one value per env, both signs occur
+
+
+@pytest.mark.parametrize("kind,n,n_obs", VARIANTS)
+def test_variant_reset_matches_oracle_stream(cuda, kind, n, n_obs):
+    from dgppo_amd import ops_env as O
+    cfg, ocfg = _mk(kind, n, n_obs)
+    B = 24
+    seeds = np.arange(1, B + 1, dtype=np.int64) * 104729 + 7
+    agent = torch.empty(B, n, 4, device=cuda)
+    goal = torch.empty(B, cfg.n_goals, 4, device=cuda)
+    obst = torch.empty(B, cfg.n_obs, cfg.obst_stride, device=cuda)
+    O.env_reset(cfg, torch.from_numpy(seeds).to(cuda), agent, goal, obst)
+    torch.cuda.synchronize()
+    wa, wg, wo = E.env_reset(ocfg, seeds)
+    np.testing.assert_array_equal(agent.cpu().numpy().view(np.uint32), wa.view(np.uint32))
+    if kind == "MPEFormation":
+        np.testing.assert_array_equal(goal.cpu().numpy().view(np.uint32), wg.view(np.uint32))
+        # obstacle rejection compares against the circle goals (device cosf / sinf): identical decisions for these seeds
+        np.testing.assert_allclose(obst.cpu().numpy(), wo, atol=0, rtol=0)
+    elif kind == "LidarLine":
+        np.testing.assert_array_equal(goal.cpu().numpy().view(np.uint32), wg.view(np.uint32))
+        np.testing.assert_allclose(obst.cpu().numpy(), wo, atol=1e-6, rtol=0)      # rectangle corners: device cosf / sinf
+    else:
+        np.testing.assert_array_equal(goal.cpu().numpy().view(np.uint32), wg.view(np.uint32))
+        np.testing.assert_array_equal(obst.cpu().numpy().view(np.uint32), wo.view(np.uint32))

@@ -213,3 +213,102 @@ def test_step_uses_pre_step_graph_for_reward_and_cost():
     np.testing.assert_array_equal(out["reward"], E.get_reward(cfg, agent, goal, act))
     h2, _ = E.lidar_sense(cfg, out["next_agent"][..., :2], obst, *tab)
     np.testing.assert_array_equal(out["next_hits"], h2)
+
+
+# ---- task variants: closed-form known answers ---------------------------------------------------------
+def test_line_goals_divide_the_segment():
+    """landmark2goal: lidar_line.py:131-136 (ends included), mpe_line.py:124-133 (n <= 3: interior points)."""
+    lm = np.array([[[0.0, 0.0, 0, 0], [1.0, 0.5, 0, 0]]], f32)
+    g5 = E.reward_goal_positions(E.EnvCfg(E.MPE_LINE, n_agents=5), lm)[0]
+    np.testing.assert_allclose(g5, [[0, 0], [.25, .125], [.5, .25], [.75, .375], [1, .5]], atol=1e-7)
+    g3 = E.reward_goal_positions(E.EnvCfg(E.MPE_LINE, n_agents=3), lm)[0]
+    np.testing.assert_allclose(g3, [[.25, .125], [.5, .25], [.75, .375]], atol=1e-7)
+    gl = E.reward_goal_positions(E.EnvCfg(E.LIDAR_LINE, n_agents=3), lm)[0]          # LidarLine: always the end-point form
+    np.testing.assert_allclose(gl, [[0, 0], [.5, .25], [1, .5]], atol=1e-7)
+    assert E.EnvCfg(E.MPE_LINE, n_agents=5).n_goals == 2 == E.EnvCfg(E.LIDAR_LINE, n_agents=5).n_goals
+
+
+def test_formation_goals_lie_on_the_comm_circle():
+    """mpe_formation.py:94-98: landmark + R [cos, sin](2 pi i / n)."""
+    cfg = E.EnvCfg(E.MPE_FORMATION, n_agents=4)
+    g = E.reward_goal_positions(cfg, np.array([[[1.0, 1.0, 0, 0]]], f32))[0]
+    np.testing.assert_allclose(g, [[1.5, 1.0], [1.0, 1.5], [0.5, 1.0], [1.0, 0.5]], atol=1e-6)
+    assert cfg.n_goals == 1 and cfg.num_nodes == 4 + 1 + 3 + 1
+
+
+def test_line_reward_closed_form():
+    """agents sitting exactly on the 3 interior goals except one displaced by 0.1: reward = -(0.1/3) 0.01 - (1/3) 0.001 - action."""
+    cfg = E.EnvCfg(E.MPE_LINE, n_agents=3)
+    lm = np.array([[[0.0, 0.0, 0, 0], [1.0, 0.0, 0, 0]]], f32)
+    agent = np.array([[[0.25, 0, 0, 0], [0.5, 0.1, 0, 0], [0.75, 0, 0, 0]]], f32)
+    act = np.zeros((1, 3, 2), f32); act[0, 0] = [0.6, 0.8]
+    r = float(E.get_reward(cfg, agent, lm, act)[0])
+    assert abs(r - (-(0.1 / 3) * 0.01 - (1 / 3) * 0.001 - (1.0 / 3) * 0.0001)) < 1e-8
+
+
+def test_connect_spread_third_cost_and_two_sided_clip():
+    """mpe_connect_spread.py:103-136: connectivity = max_i(nearest-neighbour distance_i) - connect_radius for every agent; all three
+    components get the +-0.5 margin and are clipped to [-1, 1] (the MPE base clips from below only)."""
+    cfg = E.EnvCfg(E.MPE_CONNECT_SPREAD, n_agents=3)
+    assert (cfg.n_obs, cfg.n_cost, cfg.area_size) == (1, 3, 1.0) and abs(cfg.obs_radius - 0.25) < 1e-9
+    agent = np.array([[[0.1, 0.1, 0, 0], [0.3, 0.1, 0, 0], [0.3, 0.8, 0, 0]]], f32)     # nn distances 0.2, 0.2, 0.7
+    obs = np.array([[[0.9, 0.5, 0, 0]]], f32)
+    c = E.get_cost(cfg, agent, obs)[0]
+    assert c.shape == (3, 3)
+    np.testing.assert_allclose(c[:, 2], np.clip((0.7 - 0.45) + 0.5, -1, 1), atol=1e-6)   # disconnected: positive for all
+    np.testing.assert_allclose(c[:, 0], np.clip(np.array([0.1 - 0.2, 0.1 - 0.2, 0.1 - 0.7]) - 0.5, -1, 1), atol=1e-6)
+    close = agent.copy(); close[0, 2, :2] = [0.3, 0.3]                                  # all within 0.45: connected
+    c2 = E.get_cost(cfg, close, obs)[0]
+    np.testing.assert_allclose(c2[:, 2], (0.2 - 0.45) - 0.5, atol=1e-6)
+    touching = agent.copy(); touching[0, 1, :2] = [0.1, 0.1]                            # collision: 0.1 + 0.5 stays 0.6; overlap on an
+    obs_hit = np.array([[[0.1, 0.1, 0, 0]]], f32)                                        # obstacle: 0.3 + 0.5 = 0.8 (no clip needed), but
+    assert float(E.get_cost(cfg, touching, obs_hit)[0, 0, 1]) == pytest.approx(0.8, abs=1e-6)
+    far = E.EnvCfg(E.MPE_SPREAD, n_agents=3, n_obs=1)                                     # the base class clips from below only:
+    assert float(E.get_cost(far, touching, obs_hit)[0, 0, 1]) == pytest.approx(0.6, abs=1e-6)   # car + obs radius 0.1 + 0.5
+
+
+def test_corridor_layout_masks_and_limits():
+    """mpe_corridor.py:35-39,55-56,62-65,93: obs_radius = (A - width) / 4, discs at (r, A/2) and (A - r, A/2), y may reach 2 A,
+    agent-obstacle edges are never masked."""
+    cfg = E.EnvCfg(E.MPE_CORRIDOR, n_agents=3, n_obs=7)
+    assert cfg.n_obs == 2 and abs(cfg.obs_radius - 0.2) < 1e-9 and cfg.area_size == 1.0
+    a, g, o = E.env_reset(cfg, np.array([5, 6], dtype=np.int64))
+    np.testing.assert_allclose(o[0, :, :2], [[0.2, 0.5], [0.8, 0.5]], atol=1e-7)
+    th = E.reset_thresholds(cfg)
+    assert (a[..., 1] <= th["side_y"]).all() and (g[..., 1] >= th["goal_shift_y"]).all()  # agents below, goals above the walls
+    lo, hi = E.state_limits(cfg)
+    assert hi[1] == f32(2.0) and hi[0] == f32(1.0)
+    far = a.copy(); far[..., :2] = [[0.0, 0.0], [0.0, 1.9], [1.0, 1.9]]
+    gr = E.get_graph(cfg, far, g, o, None)
+    n = 3
+    assert (gr["senders"][:, n * n + n * n:] != cfg.num_nodes - 1).all()
+
+
+@pytest.mark.parametrize("kind,n,n_obs", [(E.LIDAR_LINE, 4, 2), (E.MPE_LINE, 3, 3), (E.MPE_LINE, 5, 3), (E.MPE_FORMATION, 4, 3),
+                                           (E.MPE_CONNECT_SPREAD, 4, 1)])
+def test_variant_reset_invariants(kind, n, n_obs):
+    cfg = E.EnvCfg(kind, n_agents=n, n_obs=n_obs)
+    th = E.reset_thresholds(cfg)
+    a, g, o = E.env_reset(cfg, np.arange(11, 19, dtype=np.int64))
+    assert a.shape == (8, n, 4) and g.shape == (8, cfg.n_goals, 4) and (a[..., 2:] == 0).all() and (g[..., 2:] == 0).all()
+    for b in range(8):
+        d = np.linalg.norm(a[b, :, None, :2] - a[b, None, :, :2], axis=-1) + np.eye(n) * 9
+        assert d.min() > th["min_dist"]
+        rg = E.reward_goal_positions(cfg, g[b:b + 1])[0]
+        if kind in (E.LIDAR_LINE, E.MPE_LINE):
+            assert np.linalg.norm(g[b, 1, :2] - g[b, 0, :2]) >= th["line_min_dist"]
+        if kind == E.MPE_FORMATION:
+            lo = cfg.comm_radius + 2 * cfg.car_radius
+            assert (g[b, 0, :2] >= lo - 1e-6).all() and (g[b, 0, :2] <= cfg.area_size - lo + 1e-6).all()
+        if kind == E.MPE_CONNECT_SPREAD:
+            assert (np.sort(d, 1)[:, 0] <= cfg.connect_radius).all()
+            gd = np.linalg.norm(g[b, :, None, :2] - g[b, None, :, :2], axis=-1) + np.eye(n) * 9
+            assert (gd.min(1) <= cfg.connect_radius).all()
+            assert o[b, 0, 1] == f32(0.5) and cfg.obs_radius <= o[b, 0, 0] <= 1 - cfg.obs_radius
+        elif kind == E.LIDAR_LINE:
+            pts = np.concatenate([a[b, :, :2], rg], 0)
+            assert not E.rect_inside(pts[:, None, 0], pts[:, None, 1], o[b][None], f32(0.05 * 1.1)).any()
+        else:
+            do = np.linalg.norm(o[b, :, None, :2] - a[b, None, :, :2], axis=-1)
+            dg = np.linalg.norm(o[b, :, None, :2] - rg[None], axis=-1)
+            assert (do > cfg.car_radius + cfg.obs_radius).all() and (dg > 2 * cfg.car_radius + cfg.obs_radius).all()
