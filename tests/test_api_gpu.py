@@ -19,20 +19,24 @@ def _np(x):
     return x.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("env_id,n,obs", [("LidarSpread", 4, 2), ("MPETarget", 3, 0), ("MPESpread", 3, 3), ("LidarTarget", 3, 1)])
+@pytest.mark.parametrize("env_id,n,obs", [("LidarSpread", 4, 2), ("MPETarget", 3, 0), ("MPESpread", 3, 3), ("LidarTarget", 3, 1),
+                                          # task variants: the goal NODES are 2 landmarks / 1 landmark / n goals
+                                          ("LidarLine", 4, 2), ("MPELine", 5, 2), ("MPEFormation", 4, 3), ("MPECorridor", 3, 2),
+                                          ("MPEConnectSpread", 4, 1)])
 def test_single_graph_env_api_matches_oracle(cuda, env_id, n, obs):
     from dgppo.env import make_env
     env = make_env(env_id, n, num_obs=obs)
     ocfg = E.EnvCfg(E.KIND_NAMES[env_id], n_agents=n, n_obs=obs)
-    assert (env.state_dim, env.node_dim, env.edge_dim, env.action_dim, env.n_cost) == (4, 7, 4, 2, 2)
-    assert env.max_episode_steps == 128 and env.dt == 0.03 and env.area_size == 1.5
+    assert (env.state_dim, env.node_dim, env.edge_dim, env.action_dim, env.n_cost) == (4, 7, 4, 2, ocfg.n_cost)
+    assert env.max_episode_steps == 128 and env.dt == 0.03 and env.area_size == ocfg.area_size
+    assert env.num_goals == ocfg.n_goals and len(env.cost_components) == ocfg.n_cost and env.params["n_obs"] == ocfg.n_obs
     g = env.reset(1234)
     N_, E_ = ocfg.num_nodes, ocfg.num_edges
     assert g.nodes.shape == (N_, 7) and g.edges.shape == (E_, 4) and g.states.shape == (N_, 4)
     assert g.receivers.shape == g.senders.shape == (E_,) and g.node_type.shape == (N_,)
     assert int(g.n_node) == N_ and int(g.n_edge) == E_ and g.is_single
     np.testing.assert_array_equal(_np(g.type_states(0, n)), _np(g.states[:n]))
-    agent, goal = _np(g.type_states(0, n))[None], _np(g.type_states(1, n))[None]
+    agent, goal = _np(g.type_states(0, n))[None], _np(g.type_states(1, env.num_goals))[None]
     if ocfg.is_lidar:
         rec = np.zeros((1, obs, 16), np.float32)
         ob = g.env_states.obstacle
@@ -48,6 +52,7 @@ def test_single_graph_env_api_matches_oracle(cuda, env_id, n, obs):
     res = env.step(g, torch.from_numpy(action))
     want = E.env_step(ocfg, agent, goal, obst, hits, action[None], E.ray_table(32))
     np.testing.assert_allclose(_np(res.reward), want["reward"][0], atol=1e-7)
+    assert tuple(res.cost.shape) == (n, ocfg.n_cost)
     np.testing.assert_allclose(_np(res.cost), want["cost"][0], atol=1e-6)
     np.testing.assert_allclose(_np(res.graph.states[:n]), want["next_agent"][0], atol=1e-7)
     np.testing.assert_array_equal(_np(res.graph.receivers), want["graph"]["receivers"][0])
@@ -128,6 +133,24 @@ def test_trainer_loop_and_metrics(cuda, tmp_path):
               "policy/clip_frac", "policy/entropy", "policy/total_variation_dist", "eval/safe_data"):
         assert k in keys, k
     assert sorted(os.listdir(tmp_path / "run" / "models")) == ["0", "2"]
+
+
+@pytest.mark.parametrize("env_id,n,obs", [("LidarLine", 4, 2), ("MPELine", 3, 3), ("MPEFormation", 4, 3), ("MPECorridor", 3, 2),
+                                          ("MPEConnectSpread", 4, 1)])
+def test_variant_envs_train_through_the_algo_surface(cuda, env_id, n, obs):
+    """make_env -> make_algo -> collect -> update -> deterministic evaluation on every task variant:
+    two DGPPO iterations with finite losses, the constraint-value net sized by env.n_cost."""
+    from dgppo.env import make_env
+    env = make_env(env_id, n, max_step=16, num_obs=obs)
+    algo = _mk_algo(env, batch_size=4 * 16)
+    assert algo.engine.Vh.n_out == env.n_cost
+    for it in range(2):
+        ro = algo.collect(None, np.arange(8, dtype=np.int64) + 100 * it + 1)
+        assert tuple(ro.costs.shape) == (8, 16, n, env.n_cost) and tuple(ro.graph.states.shape[:2]) == (8, 16)
+        info = algo.update(ro, it)
+        assert all(np.isfinite(v) for v in info.values()), info
+    ev = algo.collect_deterministic(np.arange(4, dtype=np.int64) + 7, env=env)
+    assert torch.isfinite(ev.rewards).all() and tuple(ev.costs.shape) == (4, 16, n, env.n_cost)
 
 
 def test_train_py_cli(cuda, tmp_path):

@@ -32,7 +32,7 @@ def _setup(kind_name, n, n_obs, B, T_, cuda, batch_size, rnn_step, use_rnn=True,
     nc = rnn_layers if use_rnn else 0
     trees = {"policy": init.init_policy(0, cfg.node_dim, 2, 2, nc, use_lstm),
              "Vl": init.init_value(0, cfg.node_dim, 1, 2, 2, rnn_layers=nc, lstm=use_lstm),
-             "Vh": init.init_value(0, cfg.node_dim, 2, 1, 3, rnn_layers=min(nc, 1))}
+             "Vh": init.init_value(0, cfg.node_dim, cfg.n_cost, 1, 3, rnn_layers=min(nc, 1))}
     rng = np.random.default_rng(11)
     jitter = lambda tr: T.tree_map(lambda a: torch.from_numpy(a + 0.05 * rng.standard_normal(a.shape).astype(np.float32)), tr)
     trees = {k: jitter(v) for k, v in trees.items()}
@@ -138,7 +138,10 @@ def test_rollout_matches_oracle_stepwise(cuda, kind, n, n_obs):
                 np.testing.assert_array_equal(r["hits"][:, t + 1], hits)
 
 
-@pytest.mark.parametrize("kind,n,n_obs", [("LidarSpread", 3, 2), ("MPESpread", 3, 3)])
+@pytest.mark.parametrize("kind,n,n_obs", [("LidarSpread", 3, 2), ("MPESpread", 3, 3),
+                                           # task variants: 2 / 1 landmark nodes, and n_cost = 3
+                                           ("LidarLine", 4, 2), ("MPEFormation", 4, 3), ("MPEConnectSpread", 4, 1),
+                                           ("MPECorridor", 3, 2), ("MPELine", 3, 2)])
 def test_update_targets_and_gradients(cuda, kind, n, n_obs):
     B, T_, rs, bs = 4, 8, 4, 16
     cfg, ocfg, hp, eng, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs)
