@@ -299,7 +299,9 @@ def main():
         "mfma": {"flops_executed_per_step": flops_per_step, "unit": "flop (fp32, 2 per multiply-add, unpadded operand shapes)",
                  "tflops": flops_per_step / (ms_per_step * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
                  "util": flops_per_step / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                 "note": "matrix-core work of one rank's iteration / its wall time (includes rollouts, GAE and all non-MFMA time)"},
+                 "note": "network multiply-add work of one rank's iteration / its wall time (wall time includes rollouts, GAE and all "
+                         "non-MFMA kernels; < 2 % of the counted flops run on the VALU: the first GNN layer's slot-sparse attention "
+                         "and the K <= 16 dense kernels)"},
         "peaks": {"hbm_GBps": HBM_PEAK_GBS, "fp32_TFLOPs": FP32_PEAK_TFLOPS, "source": "MI355X_MICROARCH.md (spec values)",
                   "device": torch.cuda.get_device_name(device)},
         "last_info": {k: info[k] for k in ("policy/loss", "Vl/loss", "Vh/loss_Vh", "eval/safe_data")},
