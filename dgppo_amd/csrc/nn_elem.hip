@@ -9,6 +9,7 @@
 //   losses                               dgppo/algo/informarl.py:374,428-438 ; dgppo/algo/dgppo.py:310
 //   backward = jax.grad of the above     dgppo/algo/informarl.py:377,440 ; dgppo/algo/dgppo.py:316
 #include "common.h"
+#include <stdlib.h>
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -16,6 +17,25 @@ __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   return v;
+}
+// Sum of NV per-thread values over a 256-thread workgroup, then ONE atomicAdd per value.  Scalar statistics used to be
+// added with one atomic per WAVE: thousands of float atomics on the same address serialise in L2 (~7 ns each; 30 us for
+// value_loss at 262 144 elements); with a grid-stride kernel of <= 256 workgroups it is 256 atomics per value.
+template <int NV>
+__device__ inline void block_atomic_sums(const float (&v)[NV], float* dst) {
+  __shared__ float s_red[4][NV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const float w = wave_sum(v[k]);
+    if (lane == 0) s_red[wave][k] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    float t = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w][threadIdx.x];
+    atomicAdd(dst + threadIdx.x, t);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -125,7 +145,10 @@ extern "C" int32_t dgppo_ln_relu_bwd(const float* x, const float* y, const float
   DGPPO_REQUIRE(M >= 0, "ln_relu_bwd: M < 0");
   if (M == 0) return 0;
   DGPPO_REQUIRE(x && y && stats && gamma && dy && dx && dgamma && dbeta, "ln_relu_bwd: NULL operand");
-  const int grid = min(cdiv(M, 16), 1024);
+  // every workgroup ends with 128 float atomics on the same two cache lines (dgamma / dbeta): those serialise in L2, so the
+  // grid is kept at what the streaming part needs (DGPPO_LN_BWD_GRID: tuning override)
+  static const int cap = getenv("DGPPO_LN_BWD_GRID") ? atoi(getenv("DGPPO_LN_BWD_GRID")) : 256;
+  const int grid = min(cdiv(M, 16), cap);
   hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, stats, gamma, dy, dx, dgamma,
                      dbeta, M);
   DGPPO_LAUNCH_CHECK();
@@ -525,7 +548,9 @@ __device__ inline float tn_log_prob_dim(float act, float mu, float sd) {
 }
 
 __global__ void __launch_bounds__(256) policy_head_kernel(HeadArgs a) {
-  const int row_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};        // eval: sum loss, sum entropy, sum(l2 > l1), sum |ratio - 1|
+  const int rows_pad = (a.rows + 255) & ~255;
+  for (int row_raw = blockIdx.x * blockDim.x + threadIdx.x; row_raw < rows_pad; row_raw += gridDim.x * blockDim.x) {
   const bool valid = row_raw < a.rows;
   const int row = valid ? row_raw : a.rows - 1;  // invalid lanes recompute the last row and discard it (keeps waves whole)
   const float4 m = reinterpret_cast<const float4*>(a.ms)[row];
@@ -538,7 +563,7 @@ __global__ void __launch_bounds__(256) policy_head_kernel(HeadArgs a) {
       a.action[row * 2] = tanhf(mu[0]);
       a.action[row * 2 + 1] = tanhf(mu[1]);
     }
-    return;
+    continue;
   }
   float act[2];
   if (a.mode == 0) {  // sample_action: tanh(mean + std * eps); log_prob recomputes atanh(clip(a)) like the reference
@@ -548,7 +573,7 @@ __global__ void __launch_bounds__(256) policy_head_kernel(HeadArgs a) {
       a.action[row * 2 + 1] = act[1];
       a.log_pi[row] = tn_log_prob_dim(act[0], mu[0], sd[0]) + tn_log_prob_dim(act[1], mu[1], sd[1]);
     }
-    return;
+    continue;
   }
   // eval_action
   act[0] = a.action_in[row * 2];
@@ -588,7 +613,7 @@ __global__ void __launch_bounds__(256) policy_head_kernel(HeadArgs a) {
     a.log_pi[row] = lp;
     a.entropy[row] = ent;
   }
-  if (a.dms == nullptr) return;
+  if (a.dms == nullptr) continue;
   // PPO clipped surrogate (informarl.py:428-435):  mean(max(-rho A, -clip(rho) A)) - coef_ent * mean(H)
   const float A = a.adv[row];
   const float rho = expf(lp - a.log_pi_old[row]);
@@ -607,16 +632,12 @@ __global__ void __launch_bounds__(256) policy_head_kernel(HeadArgs a) {
     o.w = dsd1 * sigmoidf_(st[1] + STD_INIT_INV);
     reinterpret_cast<float4*>(a.dms)[row] = o;
   }
-  // diagnostics: wave-level partial sums, one atomic per wave
-  const float vf = valid ? 1.0f : 0.0f;
-  const float s0 = wave_sum(vf * lsel), s1 = wave_sum(vf * ent), s2 = wave_sum((valid && l2 > l1) ? 1.0f : 0.0f),
-              s3 = wave_sum(vf * fabsf(rho - 1.0f));
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(a.stats + 0, s0);
-    atomicAdd(a.stats + 1, s1);
-    atomicAdd(a.stats + 2, s2);
-    atomicAdd(a.stats + 3, s3);
+  // diagnostics: per-thread partial sums, reduced once per workgroup below
+  if (valid) {
+    acc[0] += lsel; acc[1] += ent; acc[2] += (l2 > l1) ? 1.0f : 0.0f; acc[3] += fabsf(rho - 1.0f);
   }
+  }
+  if (a.mode == 2 && a.dms != nullptr) block_atomic_sums<4>(acc, a.stats);
 }
 
 extern "C" int32_t dgppo_policy_head(const float* ms, const float* eps, const float* action_in, float* action,
@@ -637,7 +658,8 @@ extern "C" int32_t dgppo_policy_head(const float* ms, const float* eps, const fl
   a.ms = ms; a.eps = eps; a.action_in = action_in; a.action = action; a.log_pi = log_pi; a.entropy = entropy;
   a.rows = rows; a.n_agents = n_agents; a.mode = mode; a.log_pi_old = log_pi_old; a.adv = adv; a.dms = dms; a.stats = stats;
   a.clip_eps = clip_eps; a.coef_ent = coef_ent; a.inv_count = 1.0f / (float)rows;
-  hipLaunchKernelGGL(policy_head_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const int blocks = cdiv(rows, 256);
+  hipLaunchKernelGGL(policy_head_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, (hipStream_t)stream, a);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }
@@ -648,15 +670,13 @@ extern "C" int32_t dgppo_policy_head(const float* ms, const float* eps, const fl
 __global__ void __launch_bounds__(256) value_loss_kernel(const float* __restrict__ v, const float* __restrict__ target,
                                                          float* __restrict__ dv, float* __restrict__ stats, int count,
                                                          float inv_count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float l = 0.0f;
-  if (i < count) {
+  float l[1] = {0.0f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const float d = v[i] - target[i];
     dv[i] = d * inv_count;
-    l = 0.5f * d * d;
+    l[0] += 0.5f * d * d;
   }
-  l = wave_sum(l);
-  if ((threadIdx.x & 63) == 0) atomicAdd(stats, l);
+  block_atomic_sums<1>(l, stats);
 }
 
 extern "C" int32_t dgppo_value_loss(const float* v, const float* target, float* dv, float* stats, int32_t count,
@@ -664,8 +684,9 @@ extern "C" int32_t dgppo_value_loss(const float* v, const float* target, float* 
   DGPPO_REQUIRE(count >= 0, "value_loss: count < 0");
   if (count == 0) return 0;
   DGPPO_REQUIRE(v && target && dv && stats, "value_loss: NULL operand");
-  hipLaunchKernelGGL(value_loss_kernel, dim3(cdiv(count, 256)), dim3(256), 0, (hipStream_t)stream, v, target, dv, stats,
-                     count, 1.0f / (float)count);
+  const int blocks = cdiv(count, 256);
+  hipLaunchKernelGGL(value_loss_kernel, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, (hipStream_t)stream, v, target, dv,
+                     stats, count, 1.0f / (float)count);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

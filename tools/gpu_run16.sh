@@ -2,7 +2,14 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out
-timeout -k 10 1100 python3 -m pytest tests -x -q -m gpu > $O/r3h_t.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -6 $O/r3h_t.log | cut -c1-250
+timeout -k 10 600 python3 -m pytest tests/test_nn_gpu.py tests/test_algo_gpu.py -x -q -m gpu > $O/r3i_t.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -4 $O/r3i_t.log | cut -c1-250
 [ $rc -eq 0 ] || exit 1
-timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/r3h_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/r3h_smoke.log
-timeout -k 10 600 python3 bench.py > $O/r3h_bench.log 2>&1; echo "bench rc=$?"; tail -1 $O/r3h_bench.log | cut -c1-1500
+for g in 256 512 1024 2048; do echo "grid $g"; timeout -k 10 120 env DGPPO_LN_BWD_GRID=$g python3 tools/bench_nn.py elem 2>&1 | grep "ln_relu_bwd"; done
+for i in 1 2; do
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 4 --warmup 2 > $O/r3i_bench.log 2>&1
+python3 - <<'PY'
+import json
+l=[x for x in open("gpurun_out/r3i_bench.log") if x.startswith("{")]
+d=json.loads(l[-1]); print(round(d["value"]), round(d["ms_per_step"],1), d["phases_ms_per_step"])
+PY
+done
