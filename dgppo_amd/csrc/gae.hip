@@ -5,6 +5,7 @@
 //   advantage block            dgppo/algo/dgppo.py:239-259 (per-env normalisation, CBF derivative, safe gate, schedule)
 // Layout (env-major): costs [B,T,n,nh], rewards [B,T], Vh [B,T+1,n,nh], Vl [B,T+1] -> Qh [B,T,n,nh], Ql [B,T].
 #include "common.h"
+#include <stdlib.h>
 
 struct GaeArgs {
   const float* costs; const float* rewards; const float* Vh; const float* Vl;
@@ -163,6 +164,109 @@ __global__ void __launch_bounds__(256) gae_rows_kernel(GaeArgs a) {
   }
 }
 
+// Column-parallel variant (the default for lambda >= 0.5, T <= 256): the DP's rows never interact except in the final
+// lambda-weighted sum, and its columns (n*nh constraint values + the cost value) never interact at all.  So NRG adjacent
+// lanes own one (env, column) pair, each keeps RPG consecutive DP rows of that column IN REGISTERS, and a step is RPG x
+// (fma, max, select, fma) of straight-line code per lane plus a log2(NRG)-step DPP sum — no LDS, no barrier (the row-parallel
+// kernel above spends its time in a 17-value workgroup reduction per step: 1.84 ms per call at B = 4096, T = 128).
+//   * weights: c_j(ii) = lambda^(ii-j) (1-lambda)  =  lambda^(ii - j0) * [lambda^-(j-j0) (1-lambda)]  with j0 the lane's first row:
+//     the bracket is a per-register constant (lambda^-r, r < RPG <= 32, bounded by 2^31 for lambda >= 0.5), the lane keeps
+//     q = sum_r w_r row_r and a running factor f = lambda^(ii - j0) (one multiply per step); row 0's weight is 1 instead of 1-lambda.
+//   * inactive rows (j > ii) are kept at exactly 0 by the select, so they add 0 (also with NaN inputs elsewhere).
+//   * the step loop is unrolled over one row group (RPG steps), so the row that is inserted after step ii (j = ii + 1) is a
+//     compile-time register index; the lane that owns it is chosen by a comparison with the chunk index.
+// Same recurrences as compute_dec_ocp_gae (algo/utils.py:11-79); only the summation order of Q differs (fp32, ~1e-7).
+template <int NRG> __device__ inline float rg_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  if (NRG == 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  return v;
+}
+
+template <int RPG, int NRG>
+__global__ void __launch_bounds__(256) gae_cols_kernel(GaeArgs a) {
+  const int T = a.T, AH = a.AH, nh = a.nh, C = AH + 1;
+  const int rg = threadIdx.x % NRG;
+  const long item = (long)blockIdx.x * (256 / NRG) + threadIdx.x / NRG;
+  const bool valid = item < (long)a.B * C;
+  const long it = valid ? item : 0;
+  const int b = (int)(it / C), col = (int)(it - (long)b * C);
+  const bool is_l = (col == AH);
+  const int agent = is_l ? 0 : col / nh;
+  const float* costs = a.costs + (size_t)b * T * AH + agent * nh;   // + t*AH + h
+  const float* vser = is_l ? a.Vl + (size_t)b * (T + 1) : a.Vh + (size_t)b * (T + 1) * AH + col;   // V[t]: stride vstr
+  const int vstr = is_l ? 1 : AH;
+  const float* rew = a.rewards + (size_t)b * T;
+  const float lam = a.lam_pow[1], inv_lam = 1.0f / lam;
+  float w[RPG];                                       // lambda^-r (1 - lambda); row 0 of the whole DP: 1
+  {
+    float p = a.one_minus_lam;
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) { w[r] = p; p *= inv_lam; }
+    if (rg == 0) w[0] = 1.0f;
+  }
+  float row[RPG];
+#pragma unroll
+  for (int r = 0; r < RPG; ++r) row[r] = 0.0f;
+  if (rg == 0) row[0] = vser[(size_t)T * vstr];       // row 0 <- V(x_T)
+  float f = 1.0f;                                     // lambda^(ii - rg*RPG) once the group is active
+  // inputs of step t = T-1: lo (the cost itself, or -inf for the cost-value column), k ((1-gamma) max_h cost, or -reward), V[t]
+  auto fetch = [&](int t, float& lo, float& k, float& vt) {
+    vt = vser[(size_t)t * vstr];
+    if (is_l) { lo = -INFINITY; k = -rew[t]; }
+    else {
+      const float* ct = costs + (size_t)t * AH;
+      float m = ct[0];
+      for (int h = 1; h < nh; ++h) m = fmaxf(m, ct[h]);
+      lo = ct[col - agent * nh];
+      k = a.one_minus_gamma * m;
+    }
+  };
+  float lo, k, vt;
+  fetch(T - 1, lo, k, vt);
+  const int nchunk = (T + RPG - 1) / RPG;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const bool g_le = rg <= chunk, g_lt = rg < chunk;
+#pragma unroll
+    for (int s = 0; s < RPG; ++s) {
+      const int ii = chunk * RPG + s;
+      if (ii < T) {                                   // uniform
+        const int t = T - 1 - ii;
+        float lo_n = 0.0f, k_n = 0.0f, vt_n = 0.0f;
+        if (t > 0) fetch(t - 1, lo_n, k_n, vt_n);     // the next step's inputs fly under this step's arithmetic
+        float q = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RPG; ++r) {
+          const bool act = (r <= s) ? g_le : g_lt;    // row j = rg*RPG + r is active iff j <= ii
+          const float nv = fmaxf(lo, fmaf(a.gamma, row[r], k));
+          row[r] = act ? nv : row[r];
+          q = fmaf(w[r], row[r], q);
+        }
+        const float tot = rg_sum<NRG>(q * f);
+        if (valid && rg == 0) {
+          if (is_l) a.Ql[(size_t)b * T + t] = tot;
+          else a.Qh[((size_t)b * T + t) * AH + col] = tot;
+        }
+        if (g_le) f *= lam;
+        // row insertion for the next step: j = ii + 1 <- V[t]   (utils.py:53-54)
+        const int rn = (s + 1) % RPG;                 // constant after unrolling: the select below touches one register
+        const bool mine = rg == chunk + ((s + 1) / RPG);
+#pragma unroll
+        for (int r = 0; r < RPG; ++r)
+          if (r == rn) row[r] = mine ? vt : row[r];
+        lo = lo_n; k = k_n; vt = vt_n;
+      }
+    }
+  }
+}
+
+template <int RPG, int NRG>
+static void launch_gae_cols(const GaeArgs& a, hipStream_t st) {
+  const long items = (long)a.B * (a.AH + 1);
+  const int per_block = 256 / NRG;
+  hipLaunchKernelGGL((gae_cols_kernel<RPG, NRG>), dim3((unsigned)((items + per_block - 1) / per_block)), dim3(256), 0, st, a);
+}
+
 extern "C" int32_t dgppo_gae(const float* costs, const float* rewards, const float* Vh, const float* Vl,
                              const float* lam_pow, float gamma, float one_minus_gamma, float one_minus_lam, float* Qh,
                              float* Ql, int32_t B, int32_t T, int32_t n, int32_t nh, void* stream) {
@@ -170,6 +274,16 @@ extern "C" int32_t dgppo_gae(const float* costs, const float* rewards, const flo
   if (B == 0) return 0;
   DGPPO_REQUIRE(costs && rewards && Vh && Vl && lam_pow && Qh && Ql, "gae: NULL operand");
   GaeArgs a{costs, rewards, Vh, Vl, lam_pow, Qh, Ql, B, T, n * nh, n, nh, gamma, one_minus_gamma, one_minus_lam};
+  // column-parallel kernel: lambda^-31 must stay in range (lambda = 1 - one_minus_lam >= 0.5) and the rows must fit the lanes
+  if (T <= 256 && one_minus_lam <= 0.5f && one_minus_lam >= 0.0f && !getenv("DGPPO_GAE_ROWS")) {
+    hipStream_t st = (hipStream_t)stream;
+    if (T <= 32) launch_gae_cols<8, 4>(a, st);
+    else if (T <= 64) launch_gae_cols<16, 4>(a, st);
+    else if (T <= 128) launch_gae_cols<32, 4>(a, st);
+    else launch_gae_cols<32, 8>(a, st);
+    DGPPO_LAUNCH_CHECK();
+    return 0;
+  }
   if (T + 1 <= 256 && a.AH <= 32) {
     const int ahp = a.AH <= 8 ? 8 : (a.AH <= 16 ? 16 : 32);
     const size_t fsm = sizeof(float) * ((size_t)T * a.AH + (size_t)(T + 1) * a.AH + (T + 1) + T + 2 * 16 * (ahp + 1));

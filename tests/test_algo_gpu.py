@@ -8,21 +8,35 @@ from oracle import algo_ref as A
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,T,n,nh", [(7, 128, 8, 2), (3, 16, 3, 2), (2, 128, 16, 2), (4, 33, 1, 3)])
-def test_gae(cuda, B, T, n, nh):
+@pytest.mark.parametrize("B,T,n,nh,lam", [(7, 128, 8, 2, 0.95), (3, 16, 3, 2, 0.95), (2, 128, 16, 2, 0.95), (4, 33, 1, 3, 0.95),
+                                              # column-parallel kernel: every (rows per lane, lanes per column) instantiation, ragged
+                                              # last chunk, lambda at its 0.5 limit and at 1; below 0.5 the row-parallel kernels
+                                              (5, 32, 4, 3, 0.5), (3, 65, 2, 2, 1.0), (2, 200, 3, 2, 0.9), (300, 128, 8, 2, 0.97),
+                                              (3, 40, 3, 2, 0.3), (2, 7, 2, 2, 0.0)])
+def test_gae(cuda, monkeypatch, B, T, n, nh, lam):
     from dgppo_amd import ops_algo as O
     r = np.random.default_rng(B + T)
     costs = r.uniform(-1, 1, size=(B, T, n, nh)).astype(np.float32)
     rew = (-r.uniform(0, 0.02, size=(B, T))).astype(np.float32)
     Vh = r.uniform(-1, 1, size=(B, T + 1, n, nh)).astype(np.float32)
     Vl = r.uniform(0, 1, size=(B, T + 1)).astype(np.float32)
-    Qh_w, Ql_w = A.gae_batch(costs, rew, Vh, Vl, 0.99, 0.95)
+    Qh_w, Ql_w = A.gae_batch(costs[:8], rew[:8], Vh[:8], Vl[:8], 0.99, lam)       # the oracle is a Python loop: 8 envs of it
     d = lambda x: torch.from_numpy(x).to(cuda)
-    Qh = torch.empty(B, T, n, nh, device=cuda)
-    Ql = torch.empty(B, T, device=cuda)
-    O.gae(d(costs), d(rew), d(Vh), d(Vl), O.lam_pow_table(0.95, T, cuda), 0.99, 0.95, Qh, Ql)
-    np.testing.assert_allclose(Qh.cpu().numpy(), Qh_w, rtol=0, atol=1e-5)
-    np.testing.assert_allclose(Ql.cpu().numpy(), Ql_w, rtol=0, atol=1e-5)
+    outs = {}
+    for name, env in (("cols", {}), ("rows", {"DGPPO_GAE_ROWS": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        Qh = torch.full((B, T, n, nh), float("nan"), device=cuda)
+        Ql = torch.full((B, T), float("nan"), device=cuda)
+        O.gae(d(costs), d(rew), d(Vh), d(Vl), O.lam_pow_table(lam, T, cuda), 0.99, lam, Qh, Ql)
+        outs[name] = (Qh.cpu().numpy(), Ql.cpu().numpy())
+        for k in env:
+            monkeypatch.delenv(k)
+        np.testing.assert_allclose(outs[name][0][:8], Qh_w, rtol=0, atol=1e-5, err_msg=name)
+        np.testing.assert_allclose(outs[name][1][:8], Ql_w, rtol=0, atol=1e-5, err_msg=name)
+    # the two kernel families agree on every env (the oracle covers the first 8)
+    np.testing.assert_allclose(outs["cols"][0], outs["rows"][0], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(outs["cols"][1], outs["rows"][1], rtol=0, atol=1e-5)
 
 
 def test_advantage(cuda):
