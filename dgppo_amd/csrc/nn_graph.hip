@@ -269,7 +269,8 @@ __global__ void __launch_bounds__(256) attn_fwd_valu_kernel(AttnArgs a) {
     for (int s = 0; s < S; ++s) s_a[(i * S + s) * H + h] *= inv;
   }
   __syncthreads();
-  for (int idx = tid; idx < n * S * H; idx += nt) a.attn[(size_t)g * n * S * H + idx] = s_a[idx];
+  if (a.attn != nullptr)
+    for (int idx = tid; idx < n * S * H; idx += nt) a.attn[(size_t)g * n * S * H + idx] = s_a[idx];
   // aggregation of raw sender / edge features
   const int W = F + 4;
   for (int idx = tid; idx < n * H * W; idx += nt) {
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs a) {
   for (int idx = tid; idx < n * S * H; idx += 256) {
     const int h = idx % H, is = idx / H, i = is / S, s = is - i * S;
     const float av = s_a[(i * H + h) * Sp + s];
-    a.attn[(size_t)g * n * S * H + idx] = av;
+    if (a.attn != nullptr) a.attn[(size_t)g * n * S * H + idx] = av;
     if (av != 0.0f) s_L[(i * H + h) * Ll + sender_node(t, i, s)] = av;
   }
   __syncthreads();
@@ -718,7 +719,7 @@ __global__ void __launch_bounds__(256) attn_fwd_slot8_kernel(AttnArgs a) {
       const int sl = sub + 8 * j;
       if (live && sl < S) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) at[(i * S + sl) * H + h] = av[j][h];
+        for (int h = 0; h < H; ++h) if (a.attn != nullptr) at[(i * S + sl) * H + h] = av[j][h];
       }
     }
 #pragma unroll
@@ -866,6 +867,9 @@ static bool launch_attn_slot8(const AttnArgs& a, int grid, hipStream_t s, bool b
 //   * only the logit tile lives in LDS: L = Qt Xs^T is written there, the 8 lanes that own an (agent, head) pair read
 //     its logits, and overwrite the row with P in place (DS operations of one wave are ordered), then Zx = P Xs reads
 //     P as the A operand while the B operand (node rows, already in L2) is loaded directly in fragment layout.
+#ifndef DGPPO_ATTN_BWD_WPE
+#define DGPPO_ATTN_BWD_WPE 3
+#endif
 #define ATW_RT 2      // row tiles (n*H <= 32)
 #define ATW_BX 48     // registers for the node fragments of the logit GEMM: CT * F/4 <= 48
 #define ATW_BZ 48     // registers for the node fragments of the aggregation GEMM: 4*CT * ceil(F/16) <= 48
@@ -1030,7 +1034,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         const int sl = sub + 8 * j;
         if (live && sl < S) {
           const float av = l[j] * inv;
-          at[(i * S + sl) * H + h] = av;
+          if (a.attn != nullptr) at[(i * S + sl) * H + h] = av;
           if (av != 0.0f) {   // masked slots may carry 5e5 / NaN edge features: skip, never multiply
             Lrow[nd[j]] = av;
             const float4 e = efv[p][j];
@@ -1094,7 +1098,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 // DS operations of a wave execute in order, so none of these hand-overs needs a barrier.  The dXs accumulators
 // (CT x ceil(F/16) tiles) stay in registers across 2 and 3.
 template <int F, int CT, int NP, int SJ>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) attn_bwd_wave_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DGPPO_ATTN_BWD_WPE, 8))) attn_bwd_wave_kernel(AttnArgs a) {
   extern __shared__ float sm[];
   constexpr int FQ = F / 4, FT = (F + 15) / 16, KZ = CT * 4, Ll = CT * 16 + 1, RT = (NP + 1) / 2, KP = RT * 4;
   const Topo& t = a.t;
@@ -1528,7 +1532,7 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
   int32_t rc = attn_check(cfg, F, H, Kp, G, a);
   if (rc) return rc;
   if (G == 0) return 0;
-  DGPPO_REQUIRE(qt && Xa && efeat && emask && zcat && attn, "attn_fwd: NULL operand");
+  DGPPO_REQUIRE(qt && Xa && efeat && emask && zcat, "attn_fwd: NULL operand");      // attn == NULL: inference, weights not kept
   DGPPO_REQUIRE(a.t.Ns == a.t.n || Xo, "attn_fwd: Xo is NULL");
   a.qt = qt; a.Xa = Xa; a.Xo = Xo; a.efeat = efeat; a.emask = emask; a.zcat = zcat; a.attn = attn;
   const Topo& t = a.t;

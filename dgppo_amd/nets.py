@@ -211,7 +211,7 @@ class Net:
             qt = A.get(f"{tag}.qt{l}", R, H_HEADS * fp)
             K.dense_fwd(Xa, self.pp(f"gnn{l}.Mcat"), self.pp(f"gnn{l}.cvec"), qt)
             zcat = A.get(f"{tag}.zcat{l}", R, kp)
-            attn = A.get(f"{tag}.attn{l}", R, cfg.fan_in, H_HEADS)
+            attn = A.get(f"{tag}.attn{l}", R, cfg.fan_in, H_HEADS) if train else None    # only the backward reads the weights
             K.attn_fwd(cfg, fp, H_HEADS, kp, qt, Xa, Xo if Ro > 0 else None, feats.efeat, feats.emask, zcat, attn, G)
             Xa_n = A.get(f"{tag}.Xa{l + 1}", R, d)
             K.dense_fwd(zcat, self.pp(f"gnn{l}.Wout"), self.p(f"gnn{l}.bu"), Xa_n, act=1)

@@ -153,7 +153,8 @@ def attn_fwd(cfg, F, H, Kp, qt, Xa, Xo, efeat, emask, zcat, attn, G):
     N.expect_shape(qt, (G * n, H * F), "qt")
     N.expect_shape(Xa, (G * n, F), "Xa")
     N.expect_shape(zcat, (G * n, Kp), "zcat")
-    N.expect_shape(attn, (G * n, S, H), "attn")
+    if attn is not None:                                     # None: inference, the attention weights are not kept
+        N.expect_shape(attn, (G * n, S, H), "attn")
     FLOPS[0] += 2.0 * G * n * H * S * (2 * F + 4)            # logits (F) + aggregation of [x_s | e] (F + 4) per (agent, head, slot)
     rc = N.lib().dgppo_attn_fwd(C.byref(cfg), F, H, Kp, _p(qt), _p(Xa), _p(Xo), _p(efeat), _p(emask), _p(zcat), _p(attn),
                                 G, N.stream_ptr())

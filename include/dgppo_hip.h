@@ -214,7 +214,8 @@ int32_t dgppo_graph_feats(const dgppo_env_cfg* cfg, const float* agent, int64_t 
 
 /* GraphTransformer attention in fixed-fan-in form (dgppo/nn/gnn.py:85-117; jraph.segment_softmax/segment_sum):
  * qt [G*n,H*F] = x_i Mcat + cvec (a Dense), logits = qt . x_sender, masked softmax over the S slots of each agent,
- * zcat [G*n,Kp] = [x_i | per head: sum a x_s (F), sum a e (4) | 1 | 0...], attn [G*n,S,H] saved for backward.       */
+ * zcat [G*n,Kp] = [x_i | per head: sum a x_s (F), sum a e (4) | 1 | 0...], attn [G*n,S,H] saved for backward (NULL in
+ * inference: the weights are not written).                                                                          */
 int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* qt, const float* Xa,
                        const float* Xo, const float* efeat, const float* emask, float* zcat, float* attn, int32_t G,
                        void* stream);
