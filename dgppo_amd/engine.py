@@ -108,7 +108,7 @@ class OptState:
 
 class Engine:
     def __init__(self, cfg: N.EnvCfg, hyper: Hyper, device, T: int = 128,
-                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, world: int = 1, prepass_graphs: int = 1 << 16,
+                 allreduce: Optional[Callable[[torch.Tensor], None]] = None, world: int = 1, prepass_graphs: int = 1 << 20,
                  use_graphs: bool = False, multi_stream: bool = False, algo: str = "dgppo"):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
         assert algo in ("dgppo", "informarl", "hcbfcrpo", "informarl_lagr"), algo
@@ -165,7 +165,7 @@ class Engine:
         self.allreduce = allreduce
         self.world = int(world)
         assert self.world >= 1 and (allreduce is not None or self.world == 1), "world > 1 needs an allreduce"
-        self.prepass_graphs = prepass_graphs
+        self.prepass_graphs = int(os.environ.get("DGPPO_PREPASS_GRAPHS", prepass_graphs))      # tuning override
         self.ray_cos, self.ray_sin = (OE.ray_tables(cfg.n_rays, device) if cfg.is_lidar else (None, None))
         self.lam_pow = OA.lam_pow_table(hyper.gae_lambda, T, device)
         # the constant entropy noise of SURVEY A.7 (distribution.py:40: seed drawn once at trace time)
