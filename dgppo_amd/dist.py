@@ -49,10 +49,11 @@ class RcclComm:
         buf = (C.c_uint8 * ID_BYTES)()
         if rank == 0:
             N.check(lib.dgppo_comm_unique_id(buf), "dgppo_comm_unique_id")
-        idt = torch.tensor(list(buf), dtype=torch.uint8)
-        dist.broadcast(idt, src=0)                                   # host tensor over the gloo control plane
-        for i, b in enumerate(idt.tolist()):
-            buf[i] = b
+        if world > 1:
+            idt = torch.tensor(list(buf), dtype=torch.uint8)
+            dist.broadcast(idt, src=0)                               # host tensor over the gloo control plane
+            for i, b in enumerate(idt.tolist()):
+                buf[i] = b
         self._handle = C.c_void_p()
         N.check(lib.dgppo_comm_init(buf, C.c_int32(rank), C.c_int32(world), C.byref(self._handle)), "dgppo_comm_init")
 

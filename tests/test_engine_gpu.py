@@ -558,3 +558,42 @@ def test_rnn_options_targets_and_gradients(cuda, use_rnn, rnn_layers, use_lstm):
     torch.cuda.synchronize()
     _check_first_minibatch_grads(leaf, grads, ("Vl", "Vh", "policy"))
     assert info["policy/has_nan"] == 0.0
+
+
+def test_rccl_single_rank_communicator_on_hardware(cuda):
+    """The data plane of SURVEY §8(e) on real hardware as far as a one-GPU box allows: dgppo_comm_unique_id / _init /
+    _allreduce_sum_f32 / _destroy resolve librccl through dlopen, build a 1-rank communicator on this device and run the
+    collective on torch's current stream (sum over one rank = identity); then Engine(allreduce=RCCL, world=1) must walk the
+    data-parallel branch of update() (flat buffer, all-reduce, grad_scale, deterministic norm) to the same parameters as the
+    plain engine.  Multi-rank RCCL needs a multi-GPU node (the driver's SCALE run)."""
+    from dgppo_amd import dist as D, engine as EN
+    comm = D.RcclComm(0, 1)
+    x = torch.arange(1 << 16, dtype=torch.float32, device=cuda) * 0.5 - 7.0
+    want = x.clone()
+    side = torch.cuda.Stream(cuda)
+    side.wait_stream(torch.cuda.current_stream(cuda))
+    with torch.cuda.stream(side):                       # the collective follows the caller's stream
+        comm.allreduce_sum(x)
+        x.mul_(2.0)
+    side.synchronize()
+    assert torch.equal(x, want * 2.0)
+    B, T_, rs, bs = 8, 8, 4, 16
+    cfg, ocfg, hp, eng_a, trees = _setup("LidarSpread", 3, 2, B, T_, cuda, bs, rs, multi_stream=True)
+    eng_b = EN.Engine(cfg, hp, cuda, T=T_, multi_stream=True, allreduce=comm.allreduce_sum, world=1)
+    for k, net in eng_b.nets.items():
+        net.load_tree(trees[k])
+    eng_b.set_entropy_noise(77)
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    perm = np.random.default_rng(0).permutation(B)
+    infos = []
+    for eng in (eng_a, eng_b):
+        ro = eng.rollout(seeds, True, noise_seed=3)
+        det = eng.rollout(seeds + 1000, False)
+        infos.append(eng.update(ro, det, 0, perm))
+        torch.cuda.synchronize()
+    for name in eng_a.nets:
+        pa, pb = eng_a.nets[name].params, eng_b.nets[name].params
+        assert float((pa - pb).abs().max()) <= 1e-6 * max(1.0, float(pa.abs().max())), name
+    for k in infos[0]:
+        assert abs(infos[0][k] - infos[1][k]) <= 1e-5 * max(1.0, abs(infos[0][k])), k
+    comm.destroy()
