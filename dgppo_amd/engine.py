@@ -510,9 +510,10 @@ class Engine:
             Vh_mb = A.get("mb.Vh", Eb, T + 1, n, nh)
             Ah_mb = A.get("mb.Ah", Eb, T, n, nh)
 
-        def step_body():
-            """all device work of ONE minibatch (dgppo.py:276-289): gathers, the three forward/backward passes, the
-            exchange and the optimiser steps — reads the minibatch's env ids from mb_idx / mb_idx32."""
+        def body_pre():
+            """device work of ONE minibatch up to the gradient exchange (dgppo.py:276-289): gathers and the three forward /
+            backward passes (with the optimiser steps when there is no exchange) — reads the minibatch's env ids from
+            mb_idx / mb_idx32."""
             main = torch.cuda.current_stream(self.device) if is_cuda else None
             side = self._net_streams() if (self.multi_stream and main is not None) else None
             self.stats[:3].zero_()
@@ -590,22 +591,34 @@ class Engine:
                         fn()
                 for st in side:
                     main.wait_stream(st)
+
+        def body_post():
+            """after the exchange: every rank applies the identical NaN-check -> norm -> clip -> Adam (replicas stay
+            bit-identical)"""
+            self._opt_step("Vl", hp.lr_Vl)
+            if not informarl:
+                self._opt_step("Vh", hp.lr_Vh)
+            self._opt_step("policy", hp.lr_actor)
+
+        def exchange():
+            # data-parallel exchange (SURVEY §8e): ONE all-reduce(sum) of [g_policy | g_Vl | g_Vh | loss sums] per minibatch
+            # once the three backward passes have joined
+            self.allreduce(self.flat_grads[:self.n_reduced])
+
+        def step_body():
+            body_pre()
             if reduce:
-                # data-parallel exchange: ONE all-reduce(sum) of [g_policy | g_Vl | g_Vh | loss sums] per
-                # minibatch once the three backward passes have joined, then every rank applies the identical
-                # NaN-check -> norm -> clip -> Adam (replicas stay bit-identical)
-                self.allreduce(self.flat_grads[:self.n_reduced])
-                self._opt_step("Vl", hp.lr_Vl)
-                if not informarl:
-                    self._opt_step("Vh", hp.lr_Vh)
-                self._opt_step("policy", hp.lr_actor)
+                exchange()
+                body_post()
 
         # The minibatch step is ~400 launches of 10-100 us kernels: issuing them from Python costs about as much host time
         # as they take on the device.  With use_graphs the step is captured once into a HIP graph (all its operands live in
         # persistent buffers; only mb_idx changes) and replayed for every further minibatch and iteration.  Not with a
-        # gradient hook (a Python callback) or a collective in the step (captured by neither gloo nor the rehearsal path).
+        # gradient hook (a Python callback).  With a gradient exchange the step is TWO graphs — everything before the
+        # collective, and the optimiser steps after it — with the collective issued eagerly between the replays, so that no
+        # communication library call is ever recorded into a graph.
         slot = None
-        if self.use_graphs and is_cuda and self.grad_hook is None and not reduce:
+        if self.use_graphs and is_cuda and self.grad_hook is None:
             key = (self.algo, B, Eb, ro.agent.data_ptr(), det.agent.data_ptr() if det is not None else 0,
                    tg["adv"].data_ptr(), tg["Ql"].data_ptr(), mb_idx.data_ptr(), self._update_generation())
             slot = self._upd_graph
@@ -618,6 +631,9 @@ class Engine:
             mb_idx32.copy_(mb_idx)
             if slot is not None and slot.get("graph") is not None:
                 slot["graph"].replay()
+                if reduce:
+                    exchange()
+                    slot["graph_post"].replay()
                 K.FLOPS[0] += slot["flops"]
                 continue
             f0 = K.FLOPS[0]
@@ -631,7 +647,12 @@ class Engine:
                 try:
                     f1 = K.FLOPS[0]
                     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                        step_body()
+                        body_pre()
+                    if reduce:
+                        gpost = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gpost, capture_error_mode="thread_local"):
+                            body_post()
+                        slot["graph_post"] = gpost
                     K.FLOPS[0] = f1
                     slot["graph"] = graph
                 except Exception as ex:                             # keep training: eager launches are always correct

@@ -579,21 +579,25 @@ def test_rccl_single_rank_communicator_on_hardware(cuda):
     assert torch.equal(x, want * 2.0)
     B, T_, rs, bs = 8, 8, 4, 16
     cfg, ocfg, hp, eng_a, trees = _setup("LidarSpread", 3, 2, B, T_, cuda, bs, rs, multi_stream=True)
-    eng_b = EN.Engine(cfg, hp, cuda, T=T_, multi_stream=True, allreduce=comm.allreduce_sum, world=1)
+    # use_graphs: with an exchange the minibatch step is TWO captured graphs with the collective issued eagerly between their
+    # replays (no communication call is recorded into a graph)
+    eng_b = EN.Engine(cfg, hp, cuda, T=T_, multi_stream=True, use_graphs=True, allreduce=comm.allreduce_sum, world=1)
     for k, net in eng_b.nets.items():
         net.load_tree(trees[k])
     eng_b.set_entropy_noise(77)
-    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
-    perm = np.random.default_rng(0).permutation(B)
-    infos = []
-    for eng in (eng_a, eng_b):
-        ro = eng.rollout(seeds, True, noise_seed=3)
-        det = eng.rollout(seeds + 1000, False)
-        infos.append(eng.update(ro, det, 0, perm))
-        torch.cuda.synchronize()
-    for name in eng_a.nets:
-        pa, pb = eng_a.nets[name].params, eng_b.nets[name].params
-        assert float((pa - pb).abs().max()) <= 1e-6 * max(1.0, float(pa.abs().max())), name
-    for k in infos[0]:
-        assert abs(infos[0][k] - infos[1][k]) <= 1e-5 * max(1.0, abs(infos[0][k])), k
+    for it in range(3):
+        seeds = (torch.arange(1, B + 1, dtype=torch.int64, device=cuda) + 50 * it) * 7919
+        perm = np.random.default_rng(it).permutation(B)
+        infos = []
+        for eng in (eng_a, eng_b):
+            ro = eng.rollout(seeds, True, noise_seed=3 + it)
+            det = eng.rollout(seeds + 1000, False)
+            infos.append(eng.update(ro, det, it, perm))
+            torch.cuda.synchronize()
+        for name in eng_a.nets:
+            pa, pb = eng_a.nets[name].params, eng_b.nets[name].params
+            assert float((pa - pb).abs().max()) <= 1e-6 * max(1.0, float(pa.abs().max())), (it, name)
+        for k in infos[0]:
+            assert abs(infos[0][k] - infos[1][k]) <= 1e-5 * max(1.0, abs(infos[0][k])), (it, k)
+    assert eng_b._upd_graph.get("graph") is not None and eng_b._upd_graph.get("graph_post") is not None
     comm.destroy()
