@@ -258,6 +258,19 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
         else if (a.T != 1) rw = s * a.T;
         row0[rt][r] = rw;
       }
+    // the input-gate rows of step tau + 1 are requested while step tau computes (one step of latency hiding: the product of
+    // a step is ~1.5 k cycles, a global load under load more)
+    float gn[RTW][4][3];
+    auto fetch_gi = [&](int tau) {
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* gp = a.gi + (size_t)(row0[rt][r] + tau * a.n_inner) * 192 + c;
+          gn[rt][r][0] = gp[0]; gn[rt][r][1] = gp[64]; gn[rt][r][2] = gp[128];
+        }
+    };
+    fetch_gi(0);
     for (int tau = 0; tau < a.T; ++tau) {
       const float* hs_cur = sm + cur * (RB * GRU_HL);
       float* hs_nxt = sm + (cur ^ 1) * (RB * GRU_HL);
@@ -265,10 +278,8 @@ __global__ void __launch_bounds__(256) gru_fwd_kernel(GruArgs a) {
 #pragma unroll
       for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* gp = a.gi + (size_t)(row0[rt][r] + tau * a.n_inner) * 192 + c;
-          g[rt][r][0] = gp[0]; g[rt][r][1] = gp[64]; g[rt][r][2] = gp[128];
-        }
+        for (int r = 0; r < 4; ++r) { g[rt][r][0] = gn[rt][r][0]; g[rt][r][1] = gn[rt][r][1]; g[rt][r][2] = gn[rt][r][2]; }
+      if (tau + 1 < a.T) fetch_gi(tau + 1);
       __builtin_amdgcn_sched_barrier(0);
       float areg[RTW][16];
 #pragma unroll
