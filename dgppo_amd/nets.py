@@ -193,8 +193,8 @@ class Net:
                        self.pp(f"gnn{l}.cvec"), self.pp(f"gnn{l}.Wout"), f, fp, d, H_HEADS, kp)
 
     def zero_grads(self):
+        # (the prepared-weight gradients are zero between backward passes: backward() clears them after mapping them back)
         self.grads.zero_()
-        self.prep_grads.zero_()
 
     # ---- forward ---------------------------------------------------------------------------------------------------
     def forward(self, feats: GraphFeats, n_seq: int, T: int, h0: Optional[torch.Tensor], tag: str = "f",
