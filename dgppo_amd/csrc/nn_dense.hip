@@ -597,6 +597,60 @@ __global__ void __launch_bounds__(256) dense_bwd_w_reduce_kernel(const float* __
   }
 }
 
+// Deferred second stage: dgppo_dense_bwd_w_deferred launches only the partial-slab kernel and hands the description of the
+// pending reduction back to the caller, who flushes up to DGPPO_REDUCE_BATCH of them with ONE launch
+// (dgppo_dense_bwd_w_reduce_batch; blockIdx.z = reduction).  A backward pass has ~12 weight gradients: 12 reduce launches
+// of ~6 us become one.
+static thread_local dgppo_reduce_desc* g_defer = nullptr;
+
+struct ReduceBatch {
+  int n;
+  dgppo_reduce_desc d[DGPPO_REDUCE_BATCH];
+};
+
+__global__ void __launch_bounds__(256) dense_bwd_w_reduce_batch_kernel(ReduceBatch b) {
+  const dgppo_reduce_desc& d = b.d[blockIdx.z];
+  const int K = d.K, N = d.N, G = d.slabs;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int E = K * N + (d.db ? N : 0);
+  if (e >= E) return;
+  // the same split of the slabs over blockIdx.y as the single reduce kernel: splits meet in <= gridDim.y atomicAdds
+  const int splits = min((int)gridDim.y, max(1, (G + 31) / 32));
+  if ((int)blockIdx.y >= splits) return;
+  const int per = (G + splits - 1) / splits;
+  const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+  if (g0 >= g1) return;
+  const float* part = d.part;
+  const size_t st = (size_t)d.part_stride;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = g0;
+  for (; g + 3 < g1; g += 4) {
+    s0 += part[(size_t)g * st + e]; s1 += part[(size_t)(g + 1) * st + e];
+    s2 += part[(size_t)(g + 2) * st + e]; s3 += part[(size_t)(g + 3) * st + e];
+  }
+  for (; g < g1; ++g) s0 += part[(size_t)g * st + e];
+  const float sum = (s0 + s1) + (s2 + s3);
+  if (e < K * N) {
+    const int k = e / N, n = e - k * N;
+    atomicAdd(d.dW + (size_t)k * d.ldw + n, sum);
+  } else {
+    atomicAdd(d.db + (e - K * N), sum);
+  }
+}
+
+// second stage of one weight gradient: launched now, or recorded for a batched launch
+static void reduce_or_defer(hipStream_t s, const float* part, int stride, int grid, float* dW, int ldw, float* db, int K, int N) {
+  if (g_defer != nullptr) {
+    dgppo_reduce_desc& d = *g_defer;
+    d.part = part; d.part_stride = stride; d.slabs = grid; d.dW = dW; d.ldw = ldw; d.db = db; d.K = K; d.N = N; d.pending = 1;
+    return;
+  }
+  const int E = K * N + (db ? N : 0);
+  int splits = cdiv(grid, 32);
+  splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+  hipLaunchKernelGGL(dense_bwd_w_reduce_kernel, dim3(cdiv(E, 256), splits), dim3(256), 0, s, part, stride, grid, dW, ldw, db, K, N);
+}
+
 template <int NT, int KT>
 static void launch_bwd_w_kt(DenseBwdWArgs a, hipStream_t s) {
   constexpr int Kl = (KT & 1) ? KT * 16 : KT * 16 + 16;
@@ -633,13 +687,7 @@ static void launch_bwd_w_kt(DenseBwdWArgs a, hipStream_t s) {
   a.part_stride = stride;
   const int grid = cdiv(a.M, rpb);
   hipLaunchKernelGGL((dense_bwd_w_kernel<NT, KT>), dim3(grid), dim3(256), smem, s, a);
-  if (ws) {
-    const int E = a.K * a.N + (a.db ? a.N : 0);
-    int splits = cdiv(grid, 32);
-    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
-    hipLaunchKernelGGL(dense_bwd_w_reduce_kernel, dim3(cdiv(E, 256), splits), dim3(256), 0, s, ws, stride, grid, a.dW,
-                       a.ldw, a.db, a.K, a.N);
-  }
+  if (ws) reduce_or_defer(s, ws, stride, grid, a.dW, a.ldw, a.db, a.K, a.N);
 }
 
 template <int NT>
@@ -765,11 +813,7 @@ static bool launch_bwd_w_smallk(DenseBwdWArgs a, hipStream_t s) {
     if (vx) hipLaunchKernelGGL((dense_bwd_w_smallk_kernel<16, true>), dim3(grid), dim3(256), smem, s, a);
     else hipLaunchKernelGGL((dense_bwd_w_smallk_kernel<16, false>), dim3(grid), dim3(256), smem, s, a);
   }
-  const int E = a.K * a.N + (a.db ? a.N : 0);
-  int splits = cdiv(grid, 32);
-  splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
-  hipLaunchKernelGGL(dense_bwd_w_reduce_kernel, dim3(cdiv(E, 256), splits), dim3(256), 0, s, a.part, stride, grid, a.dW,
-                     a.ldw, a.db, a.K, a.N);
+  reduce_or_defer(s, a.part, stride, grid, a.dW, a.ldw, a.db, a.K, a.N);
   return true;
 }
 
@@ -805,6 +849,44 @@ extern "C" int32_t dgppo_dense_bwd_w(const float* X, int32_t ldx, const float* d
   DGPPO_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dense_bwd_w: workspace must be 16-byte aligned");
   DenseBwdWArgs a{X, ldx, dY, ldy, dW, ldw, db, M, K, N, 0, workspace, 0, (size_t)workspace_bytes};
   return dense_bwd_w_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t dgppo_dense_bwd_w_deferred(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW,
+                                              int32_t ldw, float* db, int32_t M, int32_t K, int32_t N, float* workspace,
+                                              int64_t workspace_bytes, dgppo_reduce_desc* pending, void* stream) {
+  DGPPO_REQUIRE(pending != nullptr, "dense_bwd_w_deferred: pending is NULL");
+  DGPPO_REQUIRE(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0), "dense_bwd_w: bad workspace");
+  DGPPO_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "dense_bwd_w: workspace must be 16-byte aligned");
+  pending->pending = 0;
+  DenseBwdWArgs a{X, ldx, dY, ldy, dW, ldw, db, M, K, N, 0, workspace, 0, (size_t)workspace_bytes};
+  g_defer = pending;
+  const int32_t rc = dense_bwd_w_launch(a, (hipStream_t)stream);
+  g_defer = nullptr;
+  return rc;
+}
+
+extern "C" int32_t dgppo_dense_bwd_w_reduce_batch(const dgppo_reduce_desc* descs, int32_t n, void* stream) {
+  DGPPO_REQUIRE(n >= 0 && (n == 0 || descs != nullptr), "dense_bwd_w_reduce_batch: bad arguments");
+  for (int32_t i0 = 0; i0 < n; i0 += DGPPO_REDUCE_BATCH) {
+    ReduceBatch b;
+    b.n = 0;
+    int emax = 0, gmax = 0;
+    for (int32_t i = i0; i < n && b.n < DGPPO_REDUCE_BATCH; ++i) {
+      if (!descs[i].pending) continue;
+      DGPPO_REQUIRE(descs[i].part && descs[i].dW && descs[i].slabs >= 1 && descs[i].K >= 1 && descs[i].N >= 1,
+                    "dense_bwd_w_reduce_batch: bad descriptor %d", i);
+      b.d[b.n++] = descs[i];
+      const int E = descs[i].K * descs[i].N + (descs[i].db ? descs[i].N : 0);
+      emax = E > emax ? E : emax;
+      gmax = descs[i].slabs > gmax ? descs[i].slabs : gmax;
+    }
+    if (b.n == 0) continue;
+    int splits = cdiv(gmax, 32);
+    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+    hipLaunchKernelGGL(dense_bwd_w_reduce_batch_kernel, dim3(cdiv(emax, 256), splits, b.n), dim3(256), 0, (hipStream_t)stream, b);
+  }
+  DGPPO_LAUNCH_CHECK();
+  return 0;
 }
 
 // one slab of K*N + N floats (rounded to 64) per resident workgroup; 1024 workgroups cover every instantiation's

@@ -6,6 +6,7 @@ kernels); `layout` maps flax-style names to (offset, shape).  Torch
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -355,6 +356,33 @@ class Net:
     # ---- backward --------------------------------------------------------------------------------------------------
     def backward(self, act, dout: torch.Tensor, tag: str = "b"):
         """dout = d loss / d ms [Rh,4] (policy) or d loss / d v [Rh,n_out] (values).  Accumulates into self.grads."""
+        A = self.arena
+        # the ~12 weight gradients of this pass defer their slab reductions to ONE batched launch (ops_nn.BwdWBatch); the
+        # workspace is an arena buffer sized by the first pass (a later move bumps the arena generation)
+        ws_floats = getattr(self, "_bwdw_floats", 16 << 20)
+
+        def _alloc(n_floats):
+            self._bwdw_floats = max(ws_floats, n_floats)
+            return A.get(f"{tag}.bwdw_ws", self._bwdw_floats)
+        batch = K.BwdWBatch(self.device, _alloc) if (dout.is_cuda and os.environ.get("DGPPO_NO_BWDW_BATCH") is None) else None
+        if batch is not None:
+            batch.__enter__()
+        try:
+            self._backward_body(act, dout, tag)
+        except BaseException:
+            if batch is not None:
+                batch.__exit__(RuntimeError, None, None)
+            raise
+        if batch is not None:
+            batch.__exit__(None, None, None)            # flush: the prepared-weight gradients are read below
+        for l, (f, fp, d, kp) in enumerate(self.dims):
+            q = lambda nm: self.p(f"gnn{l}.{nm}")
+            gq = lambda nm: self.g(f"gnn{l}.{nm}")
+            K.gnn_unprep(self.pg(f"gnn{l}.Mcat"), self.pg(f"gnn{l}.cvec"), self.pg(f"gnn{l}.Wout"), q("Wq"), q("bq"), q("Wk"),
+                         gq("Wq"), gq("bq"), gq("Wk"), gq("Wv"), gq("bv"), gq("We"), gq("Wu"), f, fp, d, H_HEADS, kp)
+        self.prep_grads.zero_()
+
+    def _backward_body(self, act, dout: torch.Tensor, tag: str):
         cfg, A = self.cfg, self.arena
         G, Rh, n_inner, n_seq, T = act["G"], act["Rh"], act["n_inner"], act["n_seq"], act["T"]
         n = cfg.n_agents
@@ -455,12 +483,6 @@ class Net:
                     K.dense_fwd(dXo_prev, self.pp(f"gnn{l}.Wout")[:fp], None, dXo_l, accumulate=True, trans_w=True,
                                 relu_mask=act[f"Xo{l}"])
             dXa, dXo = dXa_l, dXo_l
-        for l, (f, fp, d, kp) in enumerate(self.dims):
-            q = lambda nm: self.p(f"gnn{l}.{nm}")
-            gq = lambda nm: self.g(f"gnn{l}.{nm}")
-            K.gnn_unprep(self.pg(f"gnn{l}.Mcat"), self.pg(f"gnn{l}.cvec"), self.pg(f"gnn{l}.Wout"), q("Wq"), q("bq"), q("Wk"),
-                         gq("Wq"), gq("bq"), gq("Wk"), gq("Wv"), gq("bv"), gq("We"), gq("Wu"), f, fp, d, H_HEADS, kp)
-        self.prep_grads.zero_()
 
     # ---- flax-tree interop ----------------------------------------------------------------------------
     def load_tree(self, tree: dict):

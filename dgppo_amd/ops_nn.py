@@ -112,8 +112,63 @@ def _bwd_w_workspace(device, K: int, Ncol: int) -> torch.Tensor:
     return ws
 
 
+class ReduceDesc(C.Structure):
+    """struct dgppo_reduce_desc"""
+    _fields_ = [("part", C.c_void_p), ("dW", C.c_void_p), ("db", C.c_void_p), ("part_stride", C.c_int32), ("slabs", C.c_int32),
+                ("ldw", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("pending", C.c_int32)]
+
+
+class BwdWBatch:
+    """Weight gradients of one backward pass with their second stage (slab reduction) deferred: every dense_bwd_w inside
+    `with BwdWBatch(device, alloc):` launches only its partial-slab kernel into its own region of one workspace, and leaving
+    the block flushes all pending reductions with one launch per 16 (dgppo_dense_bwd_w_reduce_batch).  `alloc(n_floats)`
+    returns the caller's workspace of at least that size (an arena buffer: a move is visible to captured-graph checks)."""
+    _active = {}        # (device index, stream handle) -> BwdWBatch
+
+    def __init__(self, device, alloc):
+        self.device, self.alloc = device, alloc
+        self.key = None
+        self.descs = []
+        self.offset = 0                  # bytes used in the workspace
+        self.ws = None
+
+    def __enter__(self):
+        self.key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
+        if self.key in BwdWBatch._active:
+            raise RuntimeError("BwdWBatch: nested batches on one stream")
+        BwdWBatch._active[self.key] = self
+        return self
+
+    def region(self, nbytes: int):
+        """a 256-byte aligned region of the workspace; regions of one batch never overlap"""
+        nbytes = (nbytes + 255) & ~255
+        if self.ws is None or self.ws.numel() * 4 < self.offset + nbytes:
+            if self.descs:               # growing may move regions that pending reductions still read: flush them first
+                self.flush()
+            self.ws = self.alloc(max(self.offset + nbytes, 2 * (self.ws.numel() * 4 if self.ws is not None else 0)) // 4)
+        view = self.ws[self.offset // 4:(self.offset + nbytes) // 4]
+        self.offset += nbytes
+        return view
+
+    def flush(self):
+        if self.descs:
+            arr = (ReduceDesc * len(self.descs))(*self.descs)
+            N.check(N.lib().dgppo_dense_bwd_w_reduce_batch(arr, C.c_int32(len(self.descs)), N.stream_ptr()),
+                    "dgppo_dense_bwd_w_reduce_batch")
+        self.descs = []
+        self.offset = 0
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                self.flush()
+        finally:
+            BwdWBatch._active.pop(self.key, None)
+        return False
+
+
 def dense_bwd_w(X, dY, dW, db=None):
-    """dW += X.T @ dY ; db += dY.sum(0)"""
+    """dW += X.T @ dY ; db += dY.sum(0)   (inside `with BwdWBatch(...)`: the slab reduction is deferred to the batch's flush)"""
     xp, ldx, M, K = _mat(X, "X")
     yp, ldy, My, Ncol = _mat(dY, "dY")
     wp, ldw, Kw, Nw = _mat(dW, "dW")
@@ -121,8 +176,21 @@ def dense_bwd_w(X, dY, dW, db=None):
         raise ValueError(f"dense_bwd_w: shape mismatch X{tuple(X.shape)} dY{tuple(dY.shape)} dW{tuple(dW.shape)}")
     if db is not None:
         N.expect_shape(db, (Ncol,), "db")
-    ws = _bwd_w_workspace(X.device, K, Ncol)
     FLOPS[0] += 2.0 * M * K * Ncol
+    batch = BwdWBatch._active.get((X.device.index, torch.cuda.current_stream(X.device).cuda_stream)) if X.is_cuda else None
+    if batch is not None:
+        lib = N.lib()
+        lib.dgppo_dense_bwd_w_workspace_bytes.restype = C.c_int64
+        need = min(int(lib.dgppo_dense_bwd_w_workspace_bytes(C.c_int32(K), C.c_int32(Ncol))), 64 << 20)
+        ws = batch.region(need)
+        d = ReduceDesc()
+        rc = lib.dgppo_dense_bwd_w_deferred(xp, ldx, yp, ldy, wp, ldw, _p(db, "db"), M, K, Ncol, _p(ws, "workspace"),
+                                            C.c_int64(ws.numel() * 4), C.byref(d), N.stream_ptr())
+        N.check(rc, "dgppo_dense_bwd_w_deferred")
+        if d.pending:
+            batch.descs.append(d)
+        return
+    ws = _bwd_w_workspace(X.device, K, Ncol)
     rc = N.lib().dgppo_dense_bwd_w(xp, ldx, yp, ldy, wp, ldw, _p(db, "db"), M, K, Ncol, _p(ws, "workspace"),
                                    C.c_int64(ws.numel() * 4), N.stream_ptr())
     N.check(rc, "dgppo_dense_bwd_w")

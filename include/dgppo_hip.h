@@ -189,6 +189,22 @@ int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1, const flo
                          const float* W2, const float* b2, const float* g2, const float* be2, const float* Wi,
                          const float* bi, float* p1, float* y1, float* st1, float* p2, float* y2, float* st2, float* gi,
                          int32_t M, void* stream);
+/* The same weight gradient with its second stage DEFERRED: only the partial-slab kernel is launched; *pending describes the
+ * reduction that is still owed (pending->pending = 0 when the call needed none).  The caller owns the descriptors and the
+ * workspace REGION of every deferred call until it has flushed them with dgppo_dense_bwd_w_reduce_batch (one launch per
+ * DGPPO_REDUCE_BATCH reductions, on the same stream).  A backward pass has ~12 weight gradients.                    */
+#define DGPPO_REDUCE_BATCH 16
+typedef struct dgppo_reduce_desc {
+  const float* part;     /* partial slabs [slabs][part_stride] inside the caller's workspace region */
+  float* dW;             /* [K, N] with leading dimension ldw: dW += sum of the slabs               */
+  float* db;             /* [N] or NULL                                                              */
+  int32_t part_stride, slabs, ldw, K, N;
+  int32_t pending;       /* 1: this reduction is owed                                                */
+} dgppo_reduce_desc;
+int32_t dgppo_dense_bwd_w_deferred(const float* X, int32_t ldx, const float* dY, int32_t ldy, float* dW, int32_t ldw,
+                                   float* db, int32_t M, int32_t K, int32_t N, float* workspace, int64_t workspace_bytes,
+                                   dgppo_reduce_desc* pending, void* stream);
+int32_t dgppo_dense_bwd_w_reduce_batch(const dgppo_reduce_desc* descs, int32_t n, void* stream);
 /* One GRU step (T = 1) fused with the output Dense layer(s) on the same rows — the tail of a rollout step:
  * h' = GRUCell(gi, h0) (dgppo/nn/rnn.py:14-30, gi = x W_i + b_i from dgppo_mlp_gi_fwd), then either the policy head
  * u = h' W1 + b1 [64], out = u W2 + b2 (PolicyNet.head Dense -> TanhNormal Dense, dgppo/algo/module/policy.py:62-74; pass

@@ -804,3 +804,43 @@ def test_dense_bwd_w_small_k_path(cuda, M, K, N, bias):
     _close(dW, dW0.double() + X.double().T @ dY.double(), 3e-6 * math.sqrt(M), "dW small-k")
     if bias:
         _close(db, db0.double() + dY.double().sum(0), 3e-6 * math.sqrt(M), "db small-k")
+
+
+def test_dense_bwd_w_deferred_batch_equals_immediate(cuda):
+    """dgppo_dense_bwd_w_deferred + dgppo_dense_bwd_w_reduce_batch (ops_nn.BwdWBatch: one reduce launch for many weight
+    gradients, each with its own workspace region) against the immediate two-stage call: same sums, accumulation into a
+    shared dW from two calls included, the small-K and the tiny (<= 4 workgroups, atomic) paths mixed in."""
+    from dgppo_amd import nets, ops_nn as K_
+    g = torch.Generator().manual_seed(3)
+    shapes = [(20000, 64, 64, True), (20000, 64, 192, True), (9000, 144, 64, False), (20000, 8, 24, True), (100, 32, 16, True),
+              (20000, 64, 4, True)] * 3                                                      # 18 gradients: two reduce launches
+    data = [(torch.randn(M, Kd, generator=g).to(cuda), torch.randn(M, Nd, generator=g).to(cuda), b) for M, Kd, Nd, b in shapes]
+    arena = nets.Arena(cuda)
+    def run(batched, warm=False):
+        outs = [(torch.ones(X.shape[1], dY.shape[1], device=cuda), torch.ones(dY.shape[1], device=cuda) if b else None) for X, dY, b in data]
+        shared = torch.zeros(64, 64, device=cuda)                                            # two calls accumulate into it
+        big = max([0] + [v.numel() for v in arena.bufs.values()])
+        ctx = K_.BwdWBatch(cuda, lambda nf: arena.get("ws", max(nf, big))) if batched else None
+        if ctx is not None:
+            ctx.__enter__()
+        for (X, dY, b), (dW, db) in zip(data, outs):
+            K_.dense_bwd_w(X, dY, dW, db)
+        K_.dense_bwd_w(data[0][0], data[0][1], shared)
+        K_.dense_bwd_w(data[0][0], data[0][1], shared)
+        if ctx is not None:
+            if warm:                             # cold: the workspace grows (and flushes) on the way; warm: one batch at the end
+                assert len(ctx.descs) >= 16
+            ctx.__exit__(None, None, None)
+        torch.cuda.synchronize()
+        return outs, shared
+    a, sa = run(False)
+    run(True)                                    # cold pass sizes the workspace
+    b, sb = run(True, warm=True)
+    for (dWa, dba), (dWb, dbb), (X, dY, hb) in zip(a, b, data):
+        scale = float(dWa.abs().max())
+        assert float((dWa - dWb).abs().max()) <= 2e-6 * scale * math.sqrt(X.shape[0]) / 100 + 1e-5 * scale
+        if hb:
+            assert float((dba - dbb).abs().max()) <= 1e-5 * float(dba.abs().max())
+    assert float((sa - sb).abs().max()) <= 1e-5 * float(sa.abs().max())
+    want = 2.0 * (data[0][0].double().T @ data[0][1].double())
+    assert float((sb.double() - want).abs().max()) <= 3e-6 * math.sqrt(20000) * float(want.abs().max())
