@@ -272,7 +272,7 @@ class Engine:
 
     def _update_generation(self) -> int:
         """scratch buffers the minibatch step touches: the engine's arena and every network's"""
-        return self.arena.generation + sum(net.arena.generation for net in self.nets.values())
+        return self.arena.generation + sum(net.arena.generation + net.ws_arena.generation for net in self.nets.values())
 
     def _arena_generation(self) -> int:
         """scratch buffers the rollout loop touches live in the engine's arena (features) and the policy's (activations)"""

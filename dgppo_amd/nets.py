@@ -146,6 +146,8 @@ class Net:
         assert grads.shape == (self.layout.size,) and grads.is_contiguous() and grads.data_ptr() % 16 == 0
         self.grads = grads
         self.arena = Arena(device)
+        self.ws_arena = Arena(device)      # backward-only workspace (grows during the first update; the rollout graphs, which
+                                           # hold pointers into `arena`, must not be invalidated by that)
         self._views: Dict[tuple, torch.Tensor] = {}
         # per-layer dims: F (true input width), Fp (padded), D, Kp
         self.dims = []
@@ -363,7 +365,7 @@ class Net:
 
         def _alloc(n_floats):
             self._bwdw_floats = max(ws_floats, n_floats)
-            return A.get(f"{tag}.bwdw_ws", self._bwdw_floats)
+            return self.ws_arena.get(f"{tag}.bwdw_ws", self._bwdw_floats)
         batch = K.BwdWBatch(self.device, _alloc) if (dout.is_cuda and os.environ.get("DGPPO_NO_BWDW_BATCH") is None) else None
         if batch is not None:
             batch.__enter__()
