@@ -207,6 +207,24 @@ def graph_feats(cfg: N.EnvCfg, agent, agent_se, agent_st, goal, obst, hits, hits
         N.expect_shape(Xo, (G * n_other, Fp), "Xo")
     N.expect_shape(efeat, (G * n, S, 4), "efeat")
     N.expect_shape(emask, (G * n, S), "emask")
+    # the records are addressed as data_ptr + env * se + time * st (a view's own outer strides are ignored): the innermost
+    # record must be dense fp32 CUDA storage, and the storage must reach the last (env, time) the call touches
+    for name, t_, se, st, inner in (("agent", agent, agent_se, agent_st, (n, cfg.state_dim)),
+                                    ("hits", hits, hits_se, hits_st, (n, cfg.top_k, 2))):
+        if t_ is None:
+            continue
+        if not (t_.is_cuda and t_.dtype == torch.float32):
+            raise ValueError(f"graph_feats: {name} must be a float32 CUDA tensor")
+        want, acc = [], 1
+        for d in reversed(inner):
+            want.append(acc)
+            acc *= d
+        if tuple(t_.shape[-len(inner):]) != tuple(inner) or list(t_.stride()[-len(inner):]) != want[::-1]:
+            raise ValueError(f"graph_feats: the trailing {inner} block of {name} must be dense (got shape {tuple(t_.shape)}, "
+                             f"strides {t_.stride()})")
+        avail = t_.untyped_storage().nbytes() // 4 - t_.storage_offset()
+        if env_ids is None and (n_env - 1) * se + (n_time - 1) * st + acc > avail:
+            raise ValueError(f"graph_feats: {name}: the strides reach beyond its storage")
     rc = N.lib().dgppo_graph_feats(
         C.byref(cfg), C.c_void_p(agent.data_ptr()), C.c_int64(agent_se), C.c_int64(agent_st), _p(goal, "goal"),
         _p(obst, "obst") if (obst is not None and not cfg.is_lidar) else C.c_void_p(0),

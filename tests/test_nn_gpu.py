@@ -844,3 +844,64 @@ def test_dense_bwd_w_deferred_batch_equals_immediate(cuda):
     assert float((sa - sb).abs().max()) <= 1e-5 * float(sa.abs().max())
     want = 2.0 * (data[0][0].double().T @ data[0][1].double())
     assert float((sb.double() - want).abs().max()) <= 3e-6 * math.sqrt(20000) * float(want.abs().max())
+
+
+@pytest.mark.parametrize("kind,n,n_obs,G", [(E.LIDAR_SPREAD, 8, 3, 4096), (E.MPE_SPREAD, 5, 3, 512), (E.LIDAR_TARGET, 4, 2, 512)])
+def test_device_networks_are_agent_permutation_equivariant(cuda, kind, n, n_obs, G):
+    """SURVEY §8(c)(3) on the HIP path itself, at a size the oracle could not walk (4096 graphs of the benchmark topology):
+    renumbering the agents (their states, their LiDAR hits and — for the Target tasks — their goals) permutes the actor's
+    outputs and the per-agent constraint values the same way and leaves the pooled cost value unchanged.  fp32: the
+    attention sums run over the same slots in a different order (1e-5)."""
+    from dgppo_amd import nets, init
+    cfg, ocfg, ag, goal, obst, hi, _ = _scene(kind, n, n_obs, 64, 1, seed=11)
+    rep = G // 64
+    rng = np.random.default_rng(5)
+    jit = lambda a: None if a is None else (np.repeat(a, rep, axis=0) + rng.normal(scale=0.02, size=(a.shape[0] * rep,) + a.shape[1:])).astype(np.float32)
+    ag, hi = jit(ag), jit(hi)
+    goal = np.repeat(goal, rep, axis=0)
+    obst = None if obst is None else np.repeat(obst, rep, axis=0)
+    perm = rng.permutation(n)
+    ag_p = np.ascontiguousarray(ag[:, :, perm])
+    hi_p = None if hi is None else np.ascontiguousarray(hi[:, :, perm])
+    goal_p = goal if ocfg.is_spread else np.ascontiguousarray(goal[:, perm])   # Target: goal i belongs to agent i and moves with it
+    trees = {"policy": init.init_policy(3, cfg.node_dim, 2, 2), "Vl": init.init_value(4, cfg.node_dim, 1, 2, 2),
+             "Vh": init.init_value(5, cfg.node_dim, 2, 1, 3)}
+    gen = np.random.default_rng(9)
+    for kindname, n_out, layers in (("policy", 2, 2), ("Vl", 1, 2), ("Vh", 2, 1)):
+        tree = T.tree_map(lambda a: torch.from_numpy(a + 0.05 * gen.standard_normal(a.shape).astype(np.float32)), trees[kindname])
+        net = nets.Net(kindname, cfg, layers, n_out, cuda)
+        net.load_tree(tree)
+        outs = []
+        for a_, h_, g_, tag in ((ag, hi, goal, "a"), (ag_p, hi_p, goal_p, "b")):
+            feats = _feats(cfg, a_, g_, obst, h_, cuda, tag=kindname + tag)
+            act = net.forward(feats, n_seq=G * (1 if kindname == "Vl" else n), T=1, h0=None, tag="f" + tag, train=False)
+            torch.cuda.synchronize()
+            outs.append((act["ms"] if kindname == "policy" else act["v"]).clone())
+        a0, a1 = outs
+        if kindname == "Vl":
+            _close(a1, a0, 1e-5, "Vl is invariant")
+        else:
+            w = a0.shape[-1]
+            _close(a1.view(G, n, w), a0.view(G, n, w)[:, perm], 1e-5, f"{kindname} is equivariant")
+            assert float((a0.view(G, n, w)[:, perm] - a0.view(G, n, w)).abs().max()) > 1e-3      # the permutation matters
+
+
+def test_graph_feats_rejects_permuted_views(cuda):
+    """dgppo_graph_feats addresses its records as data_ptr + env * stride + time * stride: a view whose innermost record is
+    not dense (e.g. agents permuted by fancy indexing on the host and moved over as a strided tensor) must be refused, not
+    read as if it were dense."""
+    from dgppo_amd import nets
+    cfg, ocfg, ag, goal, obst, hi, _ = _scene(E.LIDAR_SPREAD, 4, 2, 3, 2, seed=1)
+    arena = nets.Arena(cuda)
+    f = nets.GraphFeats(cfg, 6, arena, "x")
+    agd = torch.from_numpy(ag).to(cuda)
+    hid = torch.from_numpy(hi).to(cuda)
+    bad = agd.transpose(2, 3)                                    # [env, T, sd, n] storage seen as [.., n, sd]: same numel, wrong layout
+    args = (torch.from_numpy(goal).to(cuda), torch.from_numpy(obst).to(cuda))
+    n, sd, k = 4, 4, cfg.top_k
+    with pytest.raises(ValueError, match="dense"):
+        f.compute(bad, 2 * n * sd, n * sd, *args, hid, 2 * n * k * 2, n * k * 2, None, 3, 2)
+    f8 = nets.GraphFeats(cfg, 8, arena, "y")
+    with pytest.raises(ValueError, match="beyond its storage"):
+        f8.compute(agd, 2 * n * sd, n * sd, *args, hid, 2 * n * k * 2, n * k * 2, None, 4, 2)       # one env too many
+    f.compute(agd, 2 * n * sd, n * sd, *args, hid, 2 * n * k * 2, n * k * 2, None, 3, 2)            # the dense record is fine
