@@ -114,3 +114,34 @@ def test_lagrangian_kernels(cuda):
     x = d(r.normal(size=(1000,)).astype(np.float32)); y = torch.empty_like(x)
     O.relu_fwd(x, y)
     assert torch.equal(y, torch.clamp_min(x, 0.0))
+
+
+def test_gae_full_size_is_positively_homogeneous(cuda):
+    """A size-independent property at the benchmark size (B = 4096 envs, T = 128, n = 8, 2 costs), where the Python oracle
+    cannot go: the Dec-OCP recursion is built from +, max and non-negative weights, so scaling costs, rewards and values by
+    2 scales Qh and Ql by 2 — exactly in fp32 (a power of two); every Qh lies between the extremes of the costs / values it
+    is a convex combination of; and with Vh = costs = 0 the constraint targets are exactly 0."""
+    from dgppo_amd import ops_algo as O
+    B, T, n, nh = 4096, 128, 8, 2
+    g = torch.Generator().manual_seed(1)
+    costs = (torch.rand(B, T, n, nh, generator=g) * 2 - 1).to(cuda)
+    rew = (-torch.rand(B, T, generator=g) * 0.02).to(cuda)
+    Vh = (torch.rand(B, T + 1, n, nh, generator=g) * 2 - 1).to(cuda)
+    Vl = torch.rand(B, T + 1, generator=g).to(cuda)
+    lp = O.lam_pow_table(0.95, T, cuda)
+
+    def run(c, r, vh, vl):
+        Qh = torch.empty(B, T, n, nh, device=cuda); Ql = torch.empty(B, T, device=cuda)
+        O.gae(c, r, vh, vl, lp, 0.99, 0.95, Qh, Ql)
+        return Qh, Ql
+    Qh1, Ql1 = run(costs, rew, Vh, Vl)
+    Qh2, Ql2 = run(2 * costs, 2 * rew, 2 * Vh, 2 * Vl)
+    torch.cuda.synchronize()
+    assert torch.equal(Qh2, 2 * Qh1) and torch.equal(Ql2, 2 * Ql1)
+    assert torch.isfinite(Qh1).all() and torch.isfinite(Ql1).all()
+    # bounds: every Qh is a convex combination of max-discounted values, so it lies between the extremes of its inputs
+    lo = torch.minimum(costs.amin(dim=1), Vh.amin(dim=1)).unsqueeze(1) - 1e-5
+    hi = torch.maximum(costs.amax(dim=1), Vh.amax(dim=1)).unsqueeze(1) + 1e-5
+    assert ((Qh1 >= lo) & (Qh1 <= hi)).all()
+    Qh0, _ = run(torch.zeros_like(costs), rew, torch.zeros_like(Vh), Vl)
+    assert float(Qh0.abs().max()) == 0.0
