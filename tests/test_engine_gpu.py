@@ -601,3 +601,57 @@ def test_rccl_single_rank_communicator_on_hardware(cuda):
             assert abs(infos[0][k] - infos[1][k]) <= 1e-5 * max(1.0, abs(infos[0][k])), (it, k)
     assert eng_b._upd_graph.get("graph") is not None and eng_b._upd_graph.get("graph_post") is not None
     comm.destroy()
+
+
+@pytest.mark.parametrize("kind,n,n_obs,B", [("MPESpread", 3, 3, 1024), ("LidarBicycleTarget", 16, 8, 1024), ("LidarSpread", 8, 3, 4096)])
+def test_baseline_configs_full_iterations_keep_their_invariants(cuda, kind, n, n_obs, B):
+    """BASELINE.json configs 2, 5 (per-GPU share) and 3 at full size — T = 128, batch_size 16384, HIP-graph replay and
+    three streams on, two complete DGPPO iterations — through properties that do not need the oracle: states stay inside
+    their limits, the bicycle's heading stays a unit vector, LiDAR hit points lie within one sensing radius of their agent
+    (or are the far-away points of missed rays),
+    costs stay in their clip range, rewards are non-positive, actions lie in [-1, 1], log-probabilities / targets /
+    advantages / losses are finite, the deterministic rollout differs from the stochastic one, parameters move."""
+    from dgppo_amd import engine as EN, init
+    T_ = 128
+    cfg, ocfg, hp0, eng0, trees = _setup(kind, n, n_obs, 4, 8, cuda, 32, 4)
+    hp = EN.Hyper(batch_size=16384, rnn_step=16, train_steps=1000)
+    eng = EN.Engine(cfg, hp, cuda, T=T_, use_graphs=True, multi_stream=True)
+    eng.policy.load_tree(init.init_policy(0, cfg.node_dim, 2, hp.actor_gnn_layers))
+    eng.Vl.load_tree(init.init_value(0, cfg.node_dim, 1, hp.Vl_gnn_layers, 2))
+    eng.Vh.load_tree(init.init_value(0, cfg.node_dim, cfg.n_cost, hp.Vh_gnn_layers, 3))
+    eng.set_entropy_noise(1)
+    p0 = {k: net.params.clone() for k, net in eng.nets.items()}
+    A, vl = ocfg.area_size, ocfg.vel_limit
+    for it in range(2):
+        seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919 + it
+        ro, det = eng.rollout_pair(seeds, seeds + 100000, noise_seed=it + 1)
+        info = eng.update(ro, det, it, np.random.default_rng(it).permutation(B))
+        assert all(np.isfinite(v) for v in info.values()), info
+        for r in (ro, det):
+            ag = r.agent                                                   # [B, T+1, n, sd]
+            assert torch.isfinite(ag).all()
+            assert float(ag[..., :2].min()) >= 0.0 and float(ag[..., :2].max()) <= A
+            if ocfg.is_bicycle:
+                assert float(((ag[..., 2] ** 2 + ag[..., 3] ** 2) - 1.0).abs().max()) <= 1e-5
+                assert float(ag[..., 4].abs().max()) <= 0.5
+            else:
+                assert float(ag[..., 2:4].abs().max()) <= vl
+            assert float(r.actions.abs().max()) <= 1.0
+            assert float(r.rewards.max()) <= 0.0 and torch.isfinite(r.rewards).all()
+            c = r.costs
+            assert not torch.isinf(c).any()
+            cf = c[torch.isfinite(c)]                                      # a NaN cost needs a NaN hit point (parallel ray): rare, legal
+            assert float(cf.min()) >= -1.0 and (not ocfg.is_lidar or float(cf.max()) <= 1.0)
+            assert int(torch.isnan(c).sum()) <= c.numel() // 1000
+            if r.has_hits:
+                d = (r.hits - ag[..., None, :2]).norm(dim=-1)
+                d = d[torch.isfinite(d)]
+                # a ray either hits within the sensing radius or misses: alpha = 1e6 puts the "hit" 5e5 away (kept unclamped
+                # by the reference, SURVEY A.13)
+                near = d <= ocfg.comm_radius * (1 + 1e-5)
+                assert bool((near | (d > 1e5)).all()) and bool(near.any())
+        assert torch.isfinite(ro.log_pis).all()
+        assert float((ro.actions - det.actions).abs().max()) > 1e-3
+    for k, net in eng.nets.items():
+        assert float((net.params - p0[k]).abs().max()) > 0 and torch.isfinite(net.params).all()
+    assert eng._upd_graph.get("graph") is not None
