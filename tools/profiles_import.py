@@ -27,7 +27,8 @@ KERNEL = "lidar_wave_kernel"
 
 
 def find(sub, suffix):
-    hits = sorted(glob.glob(f"{SRC}/{sub}/**/*{suffix}", recursive=True))
+    # (gpurun merges a call's output into the local directory without deleting older runs: take the newest file)
+    hits = sorted(glob.glob(f"{SRC}/{sub}/**/*{suffix}", recursive=True), key=os.path.getmtime)
     return hits[-1] if hits else None
 
 
