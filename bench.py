@@ -42,11 +42,20 @@ def log(msg):
 
 
 def host_threads():
+    """CPU threads this process may really use: the scheduler affinity, cut down to the cgroup CPU quota when there is one
+    (a 1-GPU box of the pool exposes all 256 host CPUs but grants a 16-CPU share)."""
     try:
         aff = len(os.sched_getaffinity(0))
     except AttributeError:
         aff = os.cpu_count() or 1
-    return max(1, min(16, aff))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(period) + 0.5))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(aff, quota) if quota else aff), aff, quota
 
 
 def parse():
@@ -61,6 +70,8 @@ def parse():
     p.add_argument("--batch-size", type=int, default=16384)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--stall-seconds", type=float, default=420.0,
+                   help="self-launched ranks (--gpus N without torchrun): stop the job when no rank has written anything for this long")
     return p.parse_args()
 
 
@@ -133,7 +144,8 @@ def cpu_baseline(seconds_budget: float):
     B, T = 256, 16
     bs = 128 * T
     out = {}
-    for label, thr in (("all", host_threads()), ("one", 1)):
+    n_thr, affinity, quota = host_threads()
+    for label, thr in (("all", n_thr), ("one", 1)):
         torch.set_num_threads(thr)
         t0 = time.time()
         train_ref.iteration("LidarSpread", 8, 3, B=B, T=T, batch_size=bs, seed=0)
@@ -145,7 +157,7 @@ def cpu_baseline(seconds_budget: float):
             break
     v, thr, dt = out["all"]
     res = {"value": v, "unit": "env-steps/s", "cores": thr, "kind": "port", "cpu_model": cpu_model(),
-           "host_cpus_visible": os.cpu_count(),
+           "host_cpus_visible": os.cpu_count(), "sched_affinity": affinity, "cgroup_cpu_quota": quota, "seconds": dt,
            "sample": f"1 full DGPPO iteration of the CPU oracle (numpy-fp32 env + torch-CPU per-edge networks + autograd), "
                      f"LidarSpread n=8 obs=3, {B} envs x {T} steps, batch {bs} (128 envs/minibatch), rnn_step 16; {dt:.1f} s; "
                      f"CPU restatement (JAX not installable offline)"}
@@ -156,28 +168,11 @@ def cpu_baseline(seconds_budget: float):
 
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` with no torchrun environment: the parent starts the N ranks itself — BEFORE it makes any GPU
-    call (it never initialises HIP) — relays rank 0's JSON line and fails if any rank fails."""
-    import socket
-    import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"[bench] ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
+    call (it never initialises HIP) — supervises them (dgppo_amd/launch.py: per-rank logs, stop everything on the first
+    failure or on a stall) and relays rank 0's JSON line."""
+    from dgppo_amd import launch
+    return launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, launch.default_log_dir(ROOT),
+                              stall_seconds=args.stall_seconds)
 
 
 def main():
@@ -200,12 +195,27 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     from dgppo_amd import _native as N, engine as EN, init, dist as D, ops_nn as K
+    if world > 1 and rank == 0:
+        log(f"multi-GPU diagnostics: world {world}, {n_dev} device(s) visible, data plane '{backend}', RCCL version "
+            f"{D.rccl_version()}, NCCL_DEBUG={os.environ.get('NCCL_DEBUG')}, HSA_ENABLE_IPC_MODE_LEGACY="
+            f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, rendezvous "
+            f"{'file store' if os.environ.get('DGPPO_RDZV_FILE') else os.environ.get('MASTER_ADDR', '?') + ':' + os.environ.get('MASTER_PORT', '?')}")
     D.init_control_plane()
+    if world > 1:
+        log(f"rank {rank}: control plane (gloo) up")
     # data plane: ONE dgppo_comm_allreduce_sum_f32 (RCCL, C ABI) of the flat gradient buffer per minibatch step
     allreduce, close_comm = D.make_allreduce(world, backend)
     if allreduce is not None:                        # first collective (connection setup) outside any timed region
+        log(f"rank {rank}: communicator up, first collective")
         allreduce(torch.zeros(1 << 16, device=device))
         torch.cuda.synchronize()
+        # known-answer all-reduce: rank r contributes r + 1, every entry must come back as world (world + 1) / 2
+        D.selfcheck_allreduce(allreduce, rank, world, device)
+        log(f"rank {rank}: all-reduce self-check passed")
+    fault_rank = os.environ.get("DGPPO_BENCH_FAULT_RANK")       # test hook: this rank dies after the communicator is up
+    if fault_rank is not None and int(fault_rank) == rank:
+        log(f"rank {rank}: DGPPO_BENCH_FAULT_RANK set — exiting with code 3 (supervision test)")
+        os._exit(3)
 
     cfg = N.make_env_cfg(N.ENV_KINDS[args.env], args.num_agents, args.obs)
     T = 128
@@ -306,6 +316,9 @@ def main():
                   "device": torch.cuda.get_device_name(device)},
         "last_info": {k: info[k] for k in ("policy/loss", "Vl/loss", "Vh/loss_Vh", "eval/safe_data")},
     }
+    if world > 1:
+        out["multi_gpu"] = {"rccl_version": D.rccl_version(), "devices_visible": n_dev, "backend": backend,
+                            "allreduce_selfcheck": "passed"}
     if rl is not None:
         traffic, tsrc = None, None
         for name in ("r02_env_step_traffic.json", "r01_env_step_traffic.json"):

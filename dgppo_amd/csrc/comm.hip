@@ -23,6 +23,7 @@ struct RcclApi {
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*CommDestroy)(rccl_comm_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;                 // optional (diagnostics only)
 };
 
 RcclApi g_api;
@@ -48,6 +49,7 @@ bool load_rccl() {
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  a.GetVersion = (decltype(a.GetVersion))dlsym(h, "ncclGetVersion");
   if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString) {
     dgppo_set_error("RCCL library lacks one of ncclGetUniqueId/CommInitRank/AllReduce/CommDestroy/GetErrorString");
     return false;
@@ -77,6 +79,18 @@ extern "C" int32_t dgppo_comm_unique_id(uint8_t* id_out) {
   const int rc = g_api.GetUniqueId(&id);
   if (rc != RCCL_SUCCESS) return rccl_fail("ncclGetUniqueId", rc);
   memcpy(id_out, id.internal, DGPPO_COMM_ID_BYTES);
+  return 0;
+}
+
+extern "C" int32_t dgppo_comm_version(int32_t* version_out) {
+  DGPPO_REQUIRE(version_out != nullptr, "comm_version: version_out is NULL");
+  *version_out = 0;
+  if (!load_rccl()) return -1;
+  if (!g_api.GetVersion) { dgppo_set_error("RCCL library has no ncclGetVersion"); return -1; }
+  int v = 0;
+  const int rc = g_api.GetVersion(&v);
+  if (rc != RCCL_SUCCESS) return rccl_fail("ncclGetVersion", rc);
+  *version_out = v;
   return 0;
 }
 

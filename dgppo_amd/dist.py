@@ -33,8 +33,45 @@ def init_control_plane(timeout_s: int = 600):
     import torch.distributed as dist
     rank, _, world = env_info()
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+        # DGPPO_RDZV_FILE (set by the self-launching drivers, `bench.py --gpus N` / `train.py --gpus N`): rendezvous through a
+        # file store instead of a TCP port picked by bind/close, which another process could take in between
+        rdzv = os.environ.get("DGPPO_RDZV_FILE")
+        kw = dict(init_method=f"file://{rdzv}", rank=rank, world_size=world) if rdzv else {}
+        # gloo reports its mesh ("[Gloo] Rank 0 is connected to ...") on fd 1; the drivers promise ONE JSON line on stdout, so
+        # fd 1 points at stderr while the group forms
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s), **kw)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, world
+
+
+def rccl_version() -> Optional[int]:
+    """ncclGetVersion of the RCCL the C ABI resolves (e.g. 22204), or None when no RCCL library can be loaded"""
+    from . import _native as N
+    v = C.c_int32(0)
+    return int(v.value) if N.lib().dgppo_comm_version(C.byref(v)) == 0 else None
+
+
+def selfcheck_allreduce(allreduce: Optional[Callable], rank: int, world: int, device, count: int = 4099) -> None:
+    """one tiny all-reduce with a known answer before anything is timed or trained on: every rank contributes rank + 1 in
+    every entry, so every entry must come back as world (world + 1) / 2.  Raises on any rank that sees something else."""
+    if allreduce is None or world <= 1:
+        return
+    x = torch.full((count,), float(rank + 1), device=device)
+    allreduce(x)
+    got = x.cpu()
+    want = world * (world + 1) / 2
+    if not bool((got == want).all()):
+        bad = int((got != want).sum())
+        raise RuntimeError(f"all-reduce self-check failed on rank {rank}/{world}: expected {want} in all {count} entries, "
+                           f"{bad} differ (first values {got[:4].tolist()})")
 
 
 class RcclComm:

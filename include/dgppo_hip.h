@@ -345,6 +345,9 @@ int32_t dgppo_clip_adam_step(float* params, const float* grads, float* m, float*
 #define DGPPO_COMM_ID_BYTES 128
 /* rank 0: a fresh rendezvous id (ncclGetUniqueId); the caller ships the 128 bytes to the other ranks out of band.   */
 int32_t dgppo_comm_unique_id(uint8_t* id_out);
+/* version code of the RCCL library the process resolved (ncclGetVersion), for the diagnostics a multi-GPU launch prints
+ * before its first collective; no device work.                                                                       */
+int32_t dgppo_comm_version(int32_t* version_out);
 /* every rank, after selecting its HIP device: join the communicator (ncclCommInitRank).  *comm_out is an opaque
  * handle owned by the library until dgppo_comm_destroy.  Collective: blocks until all `world` ranks have called it. */
 int32_t dgppo_comm_init(const uint8_t* id, int32_t rank, int32_t world, void** comm_out);
