@@ -220,7 +220,7 @@ def main():
     cfg = N.make_env_cfg(N.ENV_KINDS[args.env], args.num_agents, args.obs)
     T = 128
     hp = EN.Hyper(batch_size=args.batch_size, train_steps=1000)
-    eng = EN.Engine(cfg, hp, device, T=T, allreduce=allreduce, world=world, use_graphs=True, multi_stream=True)
+    eng = EN.Engine(cfg, hp, device, T=T, allreduce=allreduce, world=world, rank=rank, use_graphs=True, multi_stream=True)
     eng.policy.load_tree(init.init_policy(0, cfg.node_dim, 2, hp.actor_gnn_layers))
     eng.Vl.load_tree(init.init_value(0, cfg.node_dim, 1, hp.Vl_gnn_layers, 2))
     eng.Vh.load_tree(init.init_value(0, cfg.node_dim, 2, hp.Vh_gnn_layers, 3))

@@ -74,7 +74,7 @@ class DGPPO(Algorithm):
                  epoch_ppo: int = 1, clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2,
                  max_grad_norm: float = 2.0, seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16,
                  use_lstm: bool = False, alpha: float = 10.0, cbf_eps: float = 1e-2, cbf_weight: float = 1.0,
-                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, world: int = 1, **kwargs):
+                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, world: int = 1, rank: int = 0, **kwargs):
         super().__init__(env, node_dim, edge_dim, action_dim, n_agents)
         _check_rnn_options(use_rnn, use_lstm, rnn_layers)
         assert epoch_ppo >= 1
@@ -89,7 +89,8 @@ class DGPPO(Algorithm):
                            Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
-                                use_graphs=True, multi_stream=True)
+                                use_graphs=True, multi_stream=True, rank=rank)
+        self._init_dp(seed, world, rank)
         nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
         self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
         self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))
@@ -102,6 +103,31 @@ class DGPPO(Algorithm):
         self.init_rnn_state = torch.zeros(rnn_layers, n_agents, 2 if self.hp.use_lstm else 1, nets.HID, device=self.device)
         self._rng = np.random.default_rng([seed, 99])
         self._single = nets.Arena(self.device)
+
+    # ---- data parallelism: batch_size and the keys handed to collect() are this rank's SHARE; everything random
+    # that must agree across the ranks comes from generators every rank seeds identically ----
+    def _init_dp(self, seed: int, world: int, rank: int):
+        self.world, self.rank = int(world), int(rank)
+        self._perm_rng = np.random.default_rng([seed, 4242])
+        self.perm_fn = None                   # tests: B -> permutation of this rank's env indices
+
+    def _perm(self, B: int) -> np.ndarray:
+        """minibatch order of one epoch.  One device: host np.random like the reference (dgppo.py:155-156).  Several ranks: the
+        SAME permutation of the local env indices on every rank, from a generator all ranks seed identically — minibatch k
+        of the job is the union of the ranks' k-th slices."""
+        if self.perm_fn is not None:
+            return np.asarray(self.perm_fn(B))
+        if self.world == 1:
+            perm = np.arange(B)
+            np.random.shuffle(perm)
+            return perm
+        return self._perm_rng.permutation(B)
+
+    def _draw_keys(self, B_local: int) -> np.ndarray:
+        """B_local fresh keys of THIS rank out of world * B_local drawn identically on every rank (a function of the global
+        env index, so the union over the ranks is what one device would draw for the global batch)"""
+        x = self._rng.integers(1, 2 ** 62, size=B_local * self.world)
+        return x[self.rank * B_local:(self.rank + 1) * B_local]
 
     # ---- carry layout: the reference's (n_layers, n_agents, n_carries = 1, 64) <-> the engine's packed rows [n, L * 64] ----
     def _carry_dims(self):
@@ -195,7 +221,7 @@ class DGPPO(Algorithm):
         seeds = self._seeds(keys)
         # the deterministic rollout that update() needs for the constraint-value targets (dgppo.py:139-141) uses the same
         # parameters as this collect: it is launched alongside on a second stream and handed to update()
-        det_seeds = self._seeds(self._rng.integers(1, 2 ** 62, size=int(seeds.shape[0])))
+        det_seeds = self._seeds(self._draw_keys(int(seeds.shape[0])))
         ro, det = self.engine.rollout_pair(seeds, det_seeds, noise_seed=int(self._rng.integers(1, 2 ** 62)))
         self._pending_det = (ro, det)
         return self._wrap(ro)
@@ -231,12 +257,11 @@ class DGPPO(Algorithm):
         if pend is not None and pend[0] is ro:
             det = pend[1]
         else:
-            det = self.engine.rollout(self._seeds(self._rng.integers(1, 2 ** 62, size=ro.B)), False)
+            det = self.engine.rollout(self._seeds(self._draw_keys(ro.B)), False)
         info = {}
         for _ in range(self.epoch_ppo):                      # dgppo.py:154-172: every epoch reshuffles and recomputes the targets
-            perm = np.arange(ro.B)                           # with the current parameters; the det rollout is shared (:140-141)
-            np.random.shuffle(perm)                          # host np.random like the reference (dgppo.py:155-156)
-            info = self.engine.update(ro, det, int(step), perm)
+            # with the current parameters; the det rollout is shared (:140-141)
+            info = self.engine.update(ro, det, int(step), self._perm(ro.B))
         return info
 
     # ---- checkpoints: {dir}/{step}/{actor,Vl,Vh}.pkl with flax-named params (informarl_lagr.py:311-327) ----

@@ -23,7 +23,7 @@ class InforMARL(DGPPO):
                  lr_actor: float = 3e-4, lr_Vl: float = 1e-3, batch_size: int = 8192, epoch_ppo: int = 1,
                  clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2, max_grad_norm: float = 2.0,
                  seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16, use_lstm: bool = False,
-                 cost_schedule: bool = False, train_steps: int = 1e5, allreduce=None, world: int = 1, **kwargs):
+                 cost_schedule: bool = False, train_steps: int = 1e5, allreduce=None, world: int = 1, rank: int = 0, **kwargs):
         Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
         _check_rnn_options(use_rnn, use_lstm, rnn_layers)
         assert epoch_ppo >= 1
@@ -37,7 +37,8 @@ class InforMARL(DGPPO):
                            use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
-                                use_graphs=True, multi_stream=True, algo="informarl")
+                                use_graphs=True, multi_stream=True, algo="informarl", rank=rank)
+        self._init_dp(seed, world, rank)
         nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
         self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
         self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))
@@ -73,9 +74,7 @@ class InforMARL(DGPPO):
         self._last_rollouts.clear()
         info = {}
         for _ in range(self.epoch_ppo):                      # informarl.py:267-278
-            perm = np.arange(ro.B)
-            np.random.shuffle(perm)                          # host np.random like the reference (informarl.py:270-271)
-            info = self.engine.update(ro, None, int(step), perm)
+            info = self.engine.update(ro, None, int(step), self._perm(ro.B))   # host np.random on one device (informarl.py:270-271)
         return info
 
     # checkpoints: {dir}/{step}/{actor,Vl}.pkl (informarl.py:459-470)
@@ -104,7 +103,7 @@ class HCBFCRPO(InforMARL):
                  epoch_ppo: int = 1, clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2,
                  max_grad_norm: float = 2.0, seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16,
                  use_lstm: bool = False, alpha: float = 10.0, cbf_eps: float = 1e-2, cbf_weight: float = 1.0,
-                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, world: int = 1, **kwargs):
+                 train_steps: int = 1e5, cbf_schedule: bool = True, allreduce=None, world: int = 1, rank: int = 0, **kwargs):
         Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
         _check_rnn_options(use_rnn, use_lstm, rnn_layers)
         assert epoch_ppo >= 1
@@ -118,7 +117,8 @@ class HCBFCRPO(InforMARL):
                            Vh_gnn_layers=Vh_gnn_layers, use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
         self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
-                                use_graphs=True, multi_stream=True, algo="hcbfcrpo")
+                                use_graphs=True, multi_stream=True, algo="hcbfcrpo", rank=rank)
+        self._init_dp(seed, world, rank)
         nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
         self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
         self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))
@@ -144,12 +144,10 @@ class InforMARLLagr(InforMARL):
                  epoch_ppo: int = 1, clip_eps: float = 0.25, gae_lambda: float = 0.95, coef_ent: float = 1e-2,
                  max_grad_norm: float = 2.0, seed: int = 0, use_rnn: bool = True, rnn_layers: int = 1, rnn_step: int = 16,
                  use_lstm: bool = False, lagr_init: float = 0.78, lr_lagr: float = 1e-7, train_steps: int = 1e5,
-                 allreduce=None, world: int = 1, **kwargs):
+                 allreduce=None, world: int = 1, rank: int = 0, **kwargs):
         Algorithm.__init__(self, env, node_dim, edge_dim, action_dim, n_agents)
         _check_rnn_options(use_rnn, use_lstm, rnn_layers)
         assert epoch_ppo >= 1
-        if allreduce is not None:
-            raise NotImplementedError("informarl_lagr runs on one device in this build (the multiplier update is not sharded)")
         assert node_dim == env.node_dim and action_dim == 2
         self.state_dim, self.seed = state_dim, seed
         self.epoch_ppo, self.use_rnn, self.rnn_layers, self.use_lstm = epoch_ppo, use_rnn, rnn_layers, use_lstm
@@ -159,8 +157,9 @@ class InforMARLLagr(InforMARL):
                            Vl_gnn_layers=Vl_gnn_layers, Vh_gnn_layers=Vh_gnn_layers, lagr_init=lagr_init, lr_lagr=lr_lagr,
                            use_rnn=use_rnn, rnn_layers=rnn_layers, use_lstm=bool(use_lstm and use_rnn))
         self.device = env.device
-        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, use_graphs=True, multi_stream=True,
-                                algo="informarl_lagr")
+        self.engine = EN.Engine(env.cfg, self.hp, self.device, T=env.max_episode_steps, allreduce=allreduce, world=world,
+                                use_graphs=True, multi_stream=True, algo="informarl_lagr", rank=rank)
+        self._init_dp(seed, world, rank)
         nc, lstm = _n_cells(use_rnn, rnn_layers), self.hp.use_lstm
         self.engine.policy.load_tree(INIT.init_policy(seed, node_dim, action_dim, actor_gnn_layers, nc, lstm))
         self.engine.Vl.load_tree(INIT.init_value(seed, node_dim, 1, Vl_gnn_layers, 2, rnn_layers=nc, lstm=lstm))

@@ -21,6 +21,7 @@ struct ResetArgs {
   // task variants: thresholds formed on the host in double from the fp32 PARAMS and rounded once (oracle: reset_thresholds)
   float form_lo, form_hi;     // MPEFormation landmark box: comm_radius + 2 car_radius .. area - comm_radius - 2 car_radius
   float line_obs_margin;      // LidarLine: 1.1 car_radius
+  int* n_failed;              // optional: += 1 per env whose bounded rejection loops ran out (the scene is then invalid)
 };
 
 struct Stream {
@@ -125,8 +126,14 @@ __global__ void env_reset_variant_kernel(ResetArgs a) {
   const float min_dist = c.reset_min_dist, half = min_dist / 2.0f;
   const int max_iter = 1024;
   const bool connect = c.kind == DGPPO_ENV_MPE_CONNECT_SPREAD;
+  // The reference's rejection loops are unbounded; here every loop has a bound so that every thread reaches the exit.  A
+  // scene whose bound ran out is INVALID (colliding / disconnected agents): it is counted in *n_failed, which the caller
+  // checks at its next host sync (dgppo_env_reset_checked) — never silently used.
+  bool gave_up = false;
   // ---- agents (and sampled goals): bounded restarts, and for ConnectSpread the bounded connectivity rejection ----
+  bool placed = false, connected = !connect;
   for (int outer = 0; outer < (connect ? 4096 : 1); ++outer) {
+    placed = false;
     for (int attempt = 0; attempt < 64; ++attempt) {
       for (int i = 0; i < n * SD; ++i) agent[i] = 0.0f;
       for (int i = 0; i < n * GS; ++i) sgoal[i] = 0.0f;
@@ -137,16 +144,17 @@ __global__ void env_reset_variant_kernel(ResetArgs a) {
         sample_node(st, sgoal, n, GS, A, c.reset_side_y, min_dist, half, nullptr, 0, max_iter, i, it_g);
         if (it_a >= max_iter || it_g >= max_iter) { failed = true; break; }
       }
-      if (!failed) break;
+      if (!failed) { placed = true; break; }
     }
-    if (!connect) break;
+    if (!connect || !placed) break;                  // 64 restarts without a valid placement: give up (infeasible density)
     bool bad = false;
     for (int i = 0; i < n; ++i) {
       const float mda = nn_dist(agent, n, SD, i), mdg = nn_dist(sgoal, n, GS, i);
       bad = bad || (mda > c.connect_radius) || (mda < c.two_car_radius) || (mdg > c.connect_radius);
     }
-    if (!bad) break;
+    if (!bad) { connected = true; break; }
   }
+  gave_up = !placed || !connected;
   if (c.kind == DGPPO_ENV_MPE_CORRIDOR || connect) {
     for (int i = 0; i < n; ++i) goal[i * SD + 1] = goal[i * SD + 1] + c.goal_shift_y;
     if (connect) {                                   // one large disc, x uniform (mpe_connect_spread.py:91-95)
@@ -160,6 +168,7 @@ __global__ void env_reset_variant_kernel(ResetArgs a) {
       obst[0] = c.obs_radius; obst[1] = A / 2.0f;
       obst[SD] = A - c.obs_radius; obst[SD + 1] = A / 2.0f;
     }
+    if (gave_up && a.n_failed) atomicAdd(a.n_failed, 1);
     return;
   }
   // ---- landmarks ----
@@ -189,18 +198,21 @@ __global__ void env_reset_variant_kernel(ResetArgs a) {
       else if (region == 2) { rx = -cx; ry = -cy; } else { rx = cy; ry = -cx; }
       goal[0] = rx + A / 2.0f; goal[1] = ry + A / 2.0f;
     }
-    for (int it = 0; it < 100000; ++it) {
+    bool found = false;
+    for (int it = 0; it < 100000 && !found; ++it) {
       st.uniform2(u0, u1);
       goal[SD] = u0 * A; goal[SD + 1] = u1 * A;
       const float dx = goal[SD] - goal[0], dy = goal[SD + 1] - goal[1];
-      if (!(sqrtf(dx * dx + dy * dy) < md)) break;
+      found = !(sqrtf(dx * dx + dy * dy) < md);
     }
+    gave_up = gave_up || !found;
   }
   // ---- obstacles: keep clear of the agents and of the n reward goals ----
   if (lidar) {
     const float r_in = a.line_obs_margin;
     for (int o = 0; o < no; ++o) {
       float* rec = obst + o * DGPPO_RECT_STRIDE;
+      bool found = false;
       for (int it = 0; it < 100000; ++it) {
         float u0, u1;
         st.uniform2(u0, u1);
@@ -226,15 +238,16 @@ __global__ void env_reset_variant_kernel(ResetArgs a) {
           reward_goal(c, goal, SD, g, gx, gy);
           inside = inside || rect_inside_r(rec, gx, gy, r_in);
         }
-        if (!inside) break;
+        if (!inside) { found = true; break; }
       }
+      gave_up = gave_up || !found;
     }
   } else {
     const float lo = c.car_radius * 3.0f;
     const float hi = A - c.car_radius * 3.0f;
     const float thr_g = c.two_car_radius + c.obs_radius;
     for (int o = 0; o < no; ++o) {
-      bool first = true;
+      bool first = true, found = false;
       float cx = 0.0f, cy = 0.0f;
       for (int it = 0; it < 100000; ++it) {
         float u0, u1;
@@ -251,12 +264,14 @@ __global__ void env_reset_variant_kernel(ResetArgs a) {
           dg = fminf(dg, sqrtf(dx * dx + dy * dy));
         }
         const bool bad = (da <= c.car_plus_obs) || (dg <= thr_g) || (cx < lo) || (cy < lo) || (cx > hi) || (cy > hi);
-        if (!bad) break;
+        if (!bad) { found = true; break; }
       }
+      gave_up = gave_up || !found;
       for (int d = 0; d < SD; ++d) obst[o * SD + d] = 0.0f;
       obst[o * SD] = cx; obst[o * SD + 1] = cy;
     }
   }
+  if (gave_up && a.n_failed) atomicAdd(a.n_failed, 1);
 }
 
 
@@ -307,7 +322,9 @@ __global__ void env_reset_kernel(ResetArgs a) {
   const int max_iter = 1024;
   // The output rows double as the working arrays all_states / all_goals of get_node_goal_rng
   // (env/utils.py:150-151): zero rows included, so the origin's neighbourhood is excluded as in the reference.
-  // bounded restarts: every thread reaches the exit (a scene that fails 64 times keeps its last draw)
+  // bounded restarts: every thread reaches the exit; a scene that fails 64 times keeps its last draw and is counted in
+  // *n_failed (see env_reset_variant_kernel)
+  bool gave_up = true;
   for (int attempt = 0; attempt < 64; ++attempt) {
     for (int i = 0; i < n * SD; ++i) { agent[i] = 0.0f; goal[i] = 0.0f; }
     bool failed = false;
@@ -317,7 +334,7 @@ __global__ void env_reset_kernel(ResetArgs a) {
       sample_node(st, goal, n, SD, A, A, min_dist, half, lidar ? obst : nullptr, no, max_iter, i, it_g);
       if (it_a >= max_iter || it_g >= max_iter) { failed = true; break; }
     }
-    if (!failed) break;
+    if (!failed) { gave_up = false; break; }
   }
   if (bicycle) {  // lidar_bicycle_target.py:80-83
     for (int i = 0; i < n; ++i) {
@@ -333,7 +350,7 @@ __global__ void env_reset_kernel(ResetArgs a) {
     const float hi = A - c.car_radius * 3.0f;
     const float thr_g = c.two_car_radius + c.obs_radius;
     for (int o = 0; o < no; ++o) {
-      bool first = true;
+      bool first = true, found = false;
       float cx = 0.0f, cy = 0.0f;
       for (int it = 0; it < 100000; ++it) {
         float u0, u1;
@@ -348,25 +365,42 @@ __global__ void env_reset_kernel(ResetArgs a) {
           dg = fminf(dg, sqrtf(dx * dx + dy * dy));
         }
         bool bad = (da <= c.car_plus_obs) || (dg <= thr_g) || (cx < lo) || (cy < lo) || (cx > hi) || (cy > hi);
-        if (!bad) break;
+        if (!bad) { found = true; break; }
       }
+      gave_up = gave_up || !found;
       for (int d = 0; d < SD; ++d) obst[o * SD + d] = 0.0f;
       obst[o * SD] = cx; obst[o * SD + 1] = cy;
     }
   }
+  if (gave_up && a.n_failed) atomicAdd(a.n_failed, 1);
 }
 
 extern "C" int32_t dgppo_env_reset(const dgppo_env_cfg* cfg, const uint64_t* seeds, float* agent, float* goal, float* obst,
                                    int32_t B, void* stream) {
+  return dgppo_env_reset_checked(cfg, seeds, agent, goal, obst, nullptr, B, stream);
+}
+
+extern "C" int32_t dgppo_env_reset_checked(const dgppo_env_cfg* cfg, const uint64_t* seeds, float* agent, float* goal,
+                                           float* obst, int32_t* n_failed, int32_t B, void* stream) {
   int32_t rc = dgppo_validate_cfg(cfg);
   if (rc) return rc;
+  {
+    // feasibility of the rejection sampling (env/utils.py:139-244): n points with pairwise distance >= reset_min_dist in
+    // [0, area] x [0, reset_side_y].  Random sequential placement of discs jams at ~0.547 coverage; beyond one half the loops
+    // would run to their bounds on (nearly) every env — a launch that looks like a hang and yields invalid scenes.
+    const double d = cfg->reset_min_dist, ax = cfg->area_size, ay = cfg->reset_side_y > 0.0f ? cfg->reset_side_y : cfg->area_size;
+    const double cover = cfg->n_agents * 3.14159265358979 * (d / 2) * (d / 2), room = (ax + d) * (ay + d);
+    DGPPO_REQUIRE(cover <= 0.5 * room,
+                  "env_reset: %d agents with minimum separation %.3f cannot be placed in %.2f x %.2f by rejection sampling "
+                  "(disc coverage %.2f of the area; the limit used here is 0.50)", cfg->n_agents, d, ax, ay, cover / room);
+  }
   DGPPO_REQUIRE(B >= 0, "B must be >= 0");
   if (B == 0) return 0;
   DGPPO_REQUIRE(seeds && agent && goal, "seeds/agent/goal must not be NULL");
   DGPPO_REQUIRE(cfg->n_obs == 0 || obst, "obst must not be NULL when n_obs > 0");
   DGPPO_REQUIRE(cfg->n_agents <= MAX_AGENTS, "reset supports at most %d agents", MAX_AGENTS);
   ResetArgs a;
-  a.cfg = *cfg; a.seeds = seeds; a.agent = agent; a.goal = goal; a.obst = obst; a.B = B;
+  a.cfg = *cfg; a.seeds = seeds; a.agent = agent; a.goal = goal; a.obst = obst; a.B = B; a.n_failed = n_failed;
   a.form_lo = (float)((double)cfg->comm_radius + 2.0 * (double)cfg->car_radius);
   a.form_hi = (float)((double)cfg->area_size - (double)cfg->comm_radius - 2.0 * (double)cfg->car_radius);
   a.line_obs_margin = (float)((double)cfg->car_radius * 1.1);
@@ -401,6 +435,46 @@ __global__ void randn_kernel(uint64_t seed, uint64_t offset, float* out, int64_t
   }
   for (int j = 0; j < 4; ++j)
     if (q * 4 + j < n_elem) out[q * 4 + j] = z[j];
+}
+
+// one thread per (row, Philox block of the GLOBAL element index that overlaps the row's window)
+__global__ void randn_rows_kernel(uint64_t seed, float* out, int64_t rows, int64_t row_len, int64_t global_row_len,
+                                  int64_t col_offset, int64_t quads_per_row) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * quads_per_row) return;
+  const int64_t r = i / quads_per_row, j = i - r * quads_per_row;
+  const int64_t g0 = r * global_row_len + col_offset;           // first global element of this row's window
+  const uint64_t ctr = (uint64_t)(g0 / 4 + j);
+  Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 1u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float u1 = ((float)(p.v[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    float u2 = u01_from_u32(p.v[2 * h + 1]);
+    float rr = sqrtf(-2.0f * logf(u1));
+    float s, cth;
+    sincosf(6.28318530717958647692f * u2, &s, &cth);
+    z[2 * h] = rr * cth;
+    z[2 * h + 1] = rr * s;
+  }
+  for (int k = 0; k < 4; ++k) {
+    const int64_t c = (int64_t)ctr * 4 + k - g0;                 // column inside the window
+    if (c >= 0 && c < row_len) out[r * row_len + c] = z[k];
+  }
+}
+
+extern "C" int32_t dgppo_randn_rows(uint64_t seed, float* out, int64_t rows, int64_t row_len, int64_t global_row_len,
+                                    int64_t col_offset, void* stream) {
+  DGPPO_REQUIRE(rows >= 0 && row_len >= 0 && col_offset >= 0 && col_offset + row_len <= global_row_len,
+                "randn_rows: the window [col_offset, col_offset + row_len) must lie inside a row of global_row_len");
+  if (rows == 0 || row_len == 0) return 0;
+  DGPPO_REQUIRE(out, "out must not be NULL");
+  const int64_t quads_per_row = row_len / 4 + 2;                  // covers any alignment of the window
+  DGPPO_REQUIRE(rows * quads_per_row < ((int64_t)1 << 38), "randn_rows: too many elements");
+  hipLaunchKernelGGL(randn_rows_kernel, dim3((unsigned)cdiv(rows * quads_per_row, 256)), dim3(256), 0, (hipStream_t)stream,
+                     seed, out, rows, row_len, global_row_len, col_offset, quads_per_row);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int32_t dgppo_randn(uint64_t seed, uint64_t offset, float* out, int64_t n_elem, void* stream) {

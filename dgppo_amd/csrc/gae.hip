@@ -7,6 +7,11 @@
 #include "common.h"
 #include <stdlib.h>
 
+// jnp.maximum / .max(-1) propagate NaN (algo/utils.py:39-44); v_max_f32 (fmaxf) returns the other operand.  Costs can be NaN
+// (a NaN LiDAR hit point, lidar_env/base.py:180-207), and the reference then gets NaN targets, NaN losses and a skipped
+// optimiser step (optax.apply_if_finite) — so must this build.
+__device__ inline float nanmax(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+
 struct GaeArgs {
   const float* costs; const float* rewards; const float* Vh; const float* Vl;
   const float* lam_pow;  // [T+1] lambda^i
@@ -40,15 +45,17 @@ __global__ void gae_kernel(GaeArgs a) {
     __syncthreads();
     for (int ag = tid; ag < n; ag += nt) {  // discount towards max_h h  (utils.py:39-43)
       float m = hcur[ag * nh];
-      for (int h = 1; h < nh; ++h) m = fmaxf(m, hcur[ag * nh + h]);
+      for (int h = 1; h < nh; ++h) m = nanmax(m, hcur[ag * nh + h]);
       for (int h = 0; h < nh; ++h) hdis[ag * nh + h] = a.one_minus_gamma * m;
     }
     __syncthreads();
     const float l = -rew[t];
     for (int idx = tid; idx < (ii + 1) * AH; idx += nt) {
       const int c = idx % AH;
-      rowH[idx] = fmaxf(hcur[c], hdis[c] + a.gamma * rowH[idx]);
+      rowH[idx] = nanmax(hcur[c], hdis[c] + a.gamma * rowH[idx]);
     }
+    // a NaN cost (or reward) turns every ACTIVE row of its column NaN; row 0 is always active and stays in every later sum,
+    // so Q of this and of all earlier time steps is NaN — what `mask * maximum(...)` (utils.py:44, 0 * NaN = NaN) yields too
     for (int j = tid; j <= ii; j += nt) rowL[j] = l + a.gamma * rowL[j];
     __syncthreads();
     // Q = sum_j c_j row_j,  c_0 = lambda^ii, c_j = lambda^(ii-j) (1 - lambda)   (utils.py:48-60)
@@ -127,8 +134,8 @@ __global__ void __launch_bounds__(256) gae_rows_kernel(GaeArgs a) {
       if (ag < AH) {
         const int agent = ag / nh;
         float m = s_cost[t * AH + agent * nh];
-        for (int h = 1; h < nh; ++h) m = fmaxf(m, s_cost[t * AH + agent * nh + h]);
-        if (act) row[ag] = fmaxf(s_cost[t * AH + ag], a.one_minus_gamma * m + a.gamma * row[ag]);
+        for (int h = 1; h < nh; ++h) m = nanmax(m, s_cost[t * AH + agent * nh + h]);
+        if (act) row[ag] = nanmax(s_cost[t * AH + ag], a.one_minus_gamma * m + a.gamma * row[ag]);
         contrib[ag] = act ? cj * row[ag] : 0.0f;
       } else {
         contrib[ag] = 0.0f;
@@ -208,7 +215,8 @@ __global__ void __launch_bounds__(256) gae_cols_kernel(GaeArgs a) {
   float row[RPG];
 #pragma unroll
   for (int r = 0; r < RPG; ++r) row[r] = 0.0f;
-  if (rg == 0) row[0] = vser[(size_t)T * vstr];       // row 0 <- V(x_T)
+  const float vT = vser[(size_t)T * vstr];
+  if (rg == 0) row[0] = vT;                           // row 0 <- V(x_T)
   float f = 1.0f;                                     // lambda^(ii - rg*RPG) once the group is active
   // inputs of step t = T-1: lo (the cost itself, or -inf for the cost-value column), k ((1-gamma) max_h cost, or -reward), V[t]
   auto fetch = [&](int t, float& lo, float& k, float& vt) {
@@ -217,13 +225,18 @@ __global__ void __launch_bounds__(256) gae_cols_kernel(GaeArgs a) {
     else {
       const float* ct = costs + (size_t)t * AH;
       float m = ct[0];
-      for (int h = 1; h < nh; ++h) m = fmaxf(m, ct[h]);
+      for (int h = 1; h < nh; ++h) m = nanmax(m, ct[h]);
       lo = ct[col - agent * nh];
-      k = a.one_minus_gamma * m;
+      k = a.one_minus_gamma * m;                      // NaN when any component of this agent's cost is
     }
   };
   float lo, k, vt;
   fetch(T - 1, lo, k, vt);
+  // NaN inputs: jnp.maximum propagates NaN (utils.py:39-44) and fmaxf does not.  Instead of a NaN-aware max per DP row, the
+  // column carries ONE flag: a NaN cost / reward at step t turns every active row of the column NaN in the reference, row 0
+  // is always active, hence Q[t'] is NaN for every t' <= t — and likewise from the step after a NaN value is inserted as a
+  // row.  (All lanes of a column group see the same inputs, so the flag is uniform over the group.)
+  bool poison = vT != vT;
   const int nchunk = (T + RPG - 1) / RPG;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const bool g_le = rg <= chunk, g_lt = rg < chunk;
@@ -242,11 +255,14 @@ __global__ void __launch_bounds__(256) gae_cols_kernel(GaeArgs a) {
           row[r] = act ? nv : row[r];
           q = fmaf(w[r], row[r], q);
         }
-        const float tot = rg_sum<NRG>(q * f);
+        poison = poison || (lo != lo) || (k != k);
+        float tot = rg_sum<NRG>(q * f);
+        tot = poison ? __builtin_nanf("") : tot;
         if (valid && rg == 0) {
           if (is_l) a.Ql[(size_t)b * T + t] = tot;
           else a.Qh[((size_t)b * T + t) * AH + col] = tot;
         }
+        poison = poison || (vt != vt);                // V[t] becomes row ii + 1: part of every sum from the next step on
         if (g_le) f *= lam;
         // row insertion for the next step: j = ii + 1 <- V[t]   (utils.py:53-54)
         const int rn = (s + 1) % RPG;                 // constant after unrolling: the select below touches one register
@@ -510,6 +526,30 @@ extern "C" int32_t dgppo_lagr_update(const float* lp_new, const float* lp_old, c
                      Ah, sums, rows, n, nh, T, (long)vh_env_stride, one_minus_gamma);
   hipLaunchKernelGGL(lagr_apply_kernel, dim3((n * nh + 63) / 64), dim3(64), 0, (hipStream_t)stream, lagr, sums, n * nh,
                      1.0f / (float)((long)n_env * T), lr);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// the two halves of dgppo_lagr_update for the data-parallel update: every rank accumulates the sums of ITS share of the
+// minibatch, the caller all-reduces sums[n*nh], then every rank applies the identical step with the GLOBAL row count
+extern "C" int32_t dgppo_lagr_sums(const float* lp_new, const float* lp_old, const float* Vh, int64_t vh_env_stride,
+                                   const float* Ah, float* sums, int32_t n_env, int32_t T, int32_t n, int32_t nh,
+                                   float one_minus_gamma, void* stream) {
+  DGPPO_REQUIRE(n_env >= 1 && T >= 1 && n >= 1 && nh >= 1 && n * nh <= 1024, "lagr_sums: bad sizes");
+  DGPPO_REQUIRE(lp_new && lp_old && Vh && Ah && sums, "lagr_sums: NULL operand");
+  const long rows = (long)n_env * T * n;
+  const int grid = (int)((rows + 255) / 256 < 512 ? (rows + 255) / 256 : 512);
+  hipLaunchKernelGGL(lagr_sum_kernel, dim3(grid), dim3(256), sizeof(float) * n * nh, (hipStream_t)stream, lp_new, lp_old, Vh,
+                     Ah, sums, rows, n, nh, T, (long)vh_env_stride, one_minus_gamma);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t dgppo_lagr_apply(float* lagr, float* sums, int32_t count, int64_t rows_total, float lr, void* stream) {
+  DGPPO_REQUIRE(count >= 1 && count <= 1024 && rows_total >= 1, "lagr_apply: bad sizes");
+  DGPPO_REQUIRE(lagr && sums, "lagr_apply: NULL operand");
+  hipLaunchKernelGGL(lagr_apply_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, lagr, sums, count,
+                     1.0f / (float)rows_total, lr);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

@@ -148,6 +148,16 @@ def max_over_ranks(x: float, world: int) -> float:
     return float(t.item())
 
 
+def host_allreduce(x: np.ndarray, op: str, world: int) -> np.ndarray:
+    """"sum" / "max" of a small float64 host array over the control plane (identity for one rank)"""
+    if world <= 1:
+        return x
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op])
+    return t.numpy()
+
+
 def shutdown(world: int) -> None:
     if world > 1:
         import torch.distributed as dist

@@ -109,7 +109,7 @@ class OptState:
 class Engine:
     def __init__(self, cfg: N.EnvCfg, hyper: Hyper, device, T: int = 128,
                  allreduce: Optional[Callable[[torch.Tensor], None]] = None, world: int = 1, prepass_graphs: int = 1 << 20,
-                 use_graphs: bool = False, multi_stream: bool = False, algo: str = "dgppo"):
+                 use_graphs: bool = False, multi_stream: bool = False, algo: str = "dgppo", rank: int = 0):
         self.cfg, self.hp, self.device, self.T = cfg, hyper, device, T
         assert algo in ("dgppo", "informarl", "hcbfcrpo", "informarl_lagr"), algo
         # "informarl" / "hcbfcrpo": no constraint-value network and no deterministic rollout (informarl.py, hcbfcrpo.py);
@@ -163,13 +163,17 @@ class Engine:
         # allreduce(flat): in-place SUM over the data-parallel ranks of the flat buffer above (dgppo_comm_allreduce_sum_f32 on
         # the caller's stream); the 1/world is applied inside dgppo_clip_adam_step (grad_scale), not by a separate pass
         self.allreduce = allreduce
-        self.world = int(world)
+        self.world, self.rank = int(world), int(rank)
         assert self.world >= 1 and (allreduce is not None or self.world == 1), "world > 1 needs an allreduce"
+        assert 0 <= self.rank < self.world, f"rank {rank} outside world {world}"
         self.prepass_graphs = int(os.environ.get("DGPPO_PREPASS_GRAPHS", prepass_graphs))      # tuning override
         self.ray_cos, self.ray_sin = (OE.ray_tables(cfg.n_rays, device) if cfg.is_lidar else (None, None))
         self.lam_pow = OA.lam_pow_table(hyper.gae_lambda, T, device)
         # the constant entropy noise of SURVEY A.7 (distribution.py:40: seed drawn once at trace time)
         self.eps_hat = torch.zeros(cfg.n_agents, 2, device=device)
+        # envs whose reset could not place a valid scene within the kernels' loop bounds (dgppo_env_reset_checked): counted on
+        # the device by every rollout, read at the iteration's one host sync (info) — training on such a batch is an error
+        self.reset_failed = torch.zeros(1, dtype=torch.int32, device=device)
         self.grad_hook: Optional[Callable[[str, nets.Net, int], None]] = None   # (net name, net, minibatch) before the optimiser
         self._mb = 0
 
@@ -225,15 +229,17 @@ class Engine:
             ro._env_major = False
         else:
             ro = RolloutData(cfg, B, T, self.device, stochastic, self.HC)
-        OE.env_reset(cfg, seeds, ro.agent_tm[0], ro.goal, ro.obst)
+        OE.env_reset(cfg, seeds, ro.agent_tm[0], ro.goal, ro.obst, self.reset_failed)
         if ro.has_hits:
             OE.env_step(cfg, ro.agent_tm[0], None, ro.goal, ro.obst, None, self.ray_cos, self.ray_sin, None, ro.hits_tm[0],
                         None, None, None)
         ro.rnn_tm[0].zero_()                                   # init_rnn_state = zeros (informarl.py:115-124)
         eps = None
         if stochastic:
+            # the sampling noise of step t is one row of world * B * n * 2 normals, of which this rank fills the window of
+            # its envs: the union of the ranks' rollouts is the single-device rollout of the global batch
             eps = self.arena.get("ro.eps", T, B * n, 2)
-            OE.randn(noise_seed, 0, eps.view(-1))
+            OE.randn_rows(noise_seed, eps.view(T, B * n * 2), self.world * B * n * 2, self.rank * B * n * 2)
         if slot is None:
             self._rollout_steps(ro, eps, B, stochastic)
             return ro
@@ -474,7 +480,6 @@ class Engine:
         n, nh, H = cfg.n_agents, self.n_cost, nets.HID
         informarl = self.algo in ("informarl", "hcbfcrpo")          # these baselines train only Vl and the policy
         lagr = self.algo == "informarl_lagr"
-        assert not (lagr and self.allreduce is not None), "informarl_lagr is single-device in this build"
         import time as _time
         th = [_time.perf_counter()]                # host-side issue times of the phases (diagnostics: self.host_ms)
         ro.finalize()
@@ -510,6 +515,20 @@ class Engine:
             Vh_mb = A.get("mb.Vh", Eb, T + 1, n, nh)
             Ah_mb = A.get("mb.Ah", Eb, T, n, nh)
 
+        ctx = {}
+
+        def lagr_step(apply_now: bool):
+            """update_lagr (informarl_lagr.py:286-309) with the UPDATED policy: log pi of the stored actions over whole
+            episodes (zero carry), then the multiplier step — at once on one device; with a gradient exchange only this
+            rank's sums here, the all-reduce of the sums and the step follow in exchange_lagr()."""
+            full = self.policy.forward(ctx["feats"], n_seq=Eb * n, T=T, h0=None, tag="lg", train=False)
+            lp_full = A.get("mb.lp_full", R)
+            K.policy_head(full["ms"], self.eps_hat, act_mb.view(R, 2), None, lp_full, A.get("mb.ent_full", R), n, 2)
+            if apply_now:
+                OA.lagr_update(lp_full.view(Eb, T, n), lp_old_mb, Vh_mb, Ah_mb, self.lagr, self.lagr_sums, hp.gamma, hp.lr_lagr)
+            else:
+                OA.lagr_sums(lp_full.view(Eb, T, n), lp_old_mb, Vh_mb, Ah_mb, self.lagr_sums, hp.gamma)
+
         def body_pre():
             """device work of ONE minibatch up to the gradient exchange (dgppo.py:276-289): gathers and the three forward /
             backward passes (with the optimiser steps when there is no exchange) — reads the minibatch's env ids from
@@ -518,7 +537,7 @@ class Engine:
             side = self._net_streams() if (self.multi_stream and main is not None) else None
             self.stats[:3].zero_()
             # everything the three updates read is produced on the main stream first
-            feats = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=mb_idx32)
+            feats = ctx["feats"] = self._block_feats("mb", ro, 0, Eb, 0, T, env_ids=mb_idx32)
             torch.index_select(tg["Ql"], 0, mb_idx, out=Ql_mb)
             if self.algo == "dgppo":
                 feats_det = self._block_feats("mbd", det, 0, Eb, 0, T, env_ids=mb_idx32)
@@ -571,11 +590,8 @@ class Engine:
                 self.policy.backward(act, dms)
                 if not reduce:
                     self._opt_step("policy", hp.lr_actor)
-                if lagr:          # update_lagr (informarl_lagr.py:286-309) with the UPDATED policy: log pi of the stored actions
-                    full = self.policy.forward(feats, n_seq=Eb * n, T=T, h0=None, tag="lg", train=False)   # whole episodes, zero carry
-                    lp_full = A.get("mb.lp_full", R)
-                    K.policy_head(full["ms"], self.eps_hat, act_mb.view(R, 2), None, lp_full, A.get("mb.ent_full", R), n, 2)
-                    OA.lagr_update(lp_full.view(Eb, T, n), lp_old_mb, Vh_mb, Ah_mb, self.lagr, self.lagr_sums, hp.gamma, hp.lr_lagr)
+                if lagr and not reduce:
+                    lagr_step(apply_now=True)
 
             if informarl:
                 update_Vh = lambda: None                       # noqa: E731  (no constraint-value network)
@@ -599,6 +615,14 @@ class Engine:
             if not informarl:
                 self._opt_step("Vh", hp.lr_Vh)
             self._opt_step("policy", hp.lr_actor)
+            if lagr:
+                lagr_step(apply_now=False)
+
+        def exchange_lagr():
+            # the `.mean()` of the multiplier step runs over the GLOBAL minibatch: all-reduce the n * nh sums, then every rank
+            # applies the identical step (informarl_lagr.py:300-306)
+            self.allreduce(self.lagr_sums)
+            OA.lagr_apply(self.lagr, self.lagr_sums, self.world * Eb * T, hp.lr_lagr)
 
         def exchange():
             # data-parallel exchange: ONE all-reduce(sum) of [g_policy | g_Vl | g_Vh | loss sums] per minibatch
@@ -610,6 +634,8 @@ class Engine:
             if reduce:
                 exchange()
                 body_post()
+                if lagr:
+                    exchange_lagr()
 
         # The minibatch step is ~400 launches of 10-100 us kernels: issuing them from Python costs about as much host time
         # as they take on the device.  With use_graphs the step is captured once into a HIP graph (all its operands live in
@@ -634,6 +660,8 @@ class Engine:
                 if reduce:
                     exchange()
                     slot["graph_post"].replay()
+                    if lagr:
+                        exchange_lagr()
                 K.FLOPS[0] += slot["flops"]
                 continue
             f0 = K.FLOPS[0]
@@ -670,27 +698,41 @@ class Engine:
         return out
 
     def info(self, ro: RolloutData) -> dict:
-        """scalars of the LAST minibatch (dgppo.py:292) with the reference's key names; one host sync."""
+        """scalars of the LAST minibatch (dgppo.py:292) with the reference's key names; one host sync.  Under data
+        parallelism every value is GLOBAL: the loss / metric sums (stats rows 0..2) travelled with the gradients, the safe
+        count and the target / log-pi extrema are reduced here over the host control plane (two tiny gloo collectives)."""
+        from . import dist as D
         L = self._last
         s = self.stats.cpu().numpy().copy()
+        n_bad = int(self.reset_failed.item())
+        if n_bad:
+            self.reset_failed.zero_()
+            raise RuntimeError(f"env reset: {n_bad} environment(s) of the last rollouts got no valid scene within the kernels' "
+                               f"rejection-loop bounds (too many agents / obstacles for the area?) — the batch is invalid")
         s[:3] /= self.world                                   # rows 0..2 were summed over the ranks with the gradients
         G, R, nh, B = L["G"], L["R"], L["nh"], L["B"]
         o = {k: self.opt[k].state[:8].cpu().numpy() for k in self.opt}
         pol_loss = s[2, 0] / R - self.hp.coef_ent * s[2, 1] / R
+        lagr = self.algo == "informarl_lagr"
+        ext = [float(L["Ql_mb"].max()), -float(L["Ql_mb"].min()), -float(ro.log_pis.min())]
+        if lagr:
+            ext += [float(L["Qh_mb"].max()), -float(L["Qh_mb"].min())]
+        ext = D.host_allreduce(np.asarray(ext, np.float64), "max", self.world)
+        safe = float(D.host_allreduce(np.asarray([s[3, 0]], np.float64), "sum", self.world)[0])
         out = {
             "Vl/loss": float(s[0, 0] / G), "Vl/grad_norm": float(o["Vl"][4]), "Vl/has_nan": float(o["Vl"][5]),
-            "Vl/max_target": float(L["Ql_mb"].max()), "Vl/min_target": float(L["Ql_mb"].min()),
+            "Vl/max_target": float(ext[0]), "Vl/min_target": float(-ext[1]),
             "policy/loss": float(pol_loss), "policy/grad_norm": float(o["policy"][4]), "policy/has_nan": float(o["policy"][5]),
-            "policy/log_pi_min": float(ro.log_pis.min()), "policy/clip_frac": float(s[2, 2] / R),
+            "policy/log_pi_min": float(-ext[2]), "policy/clip_frac": float(s[2, 2] / R),
             "policy/entropy": float(s[2, 1] / R), "policy/total_variation_dist": float(0.5 * s[2, 3] / R),
         }
-        if self.algo == "informarl_lagr":   # informarl_lagr.py:278-282,309
+        if lagr:   # informarl_lagr.py:278-282,309
             out.update({"Vh/loss": float(s[1, 0] / (R * nh)), "Vh/grad_norm": float(o["Vh"][4]), "Vh/has_nan": float(o["Vh"][5]),
-                        "Vh/max_target": float(L["Qh_mb"].max()), "Vh/min_target": float(L["Qh_mb"].min()),
+                        "Vh/max_target": float(ext[3]), "Vh/min_target": float(-ext[4]),
                         "policy/lagr_mean": float(self.lagr.mean())})
         if self.algo == "dgppo":       # InforMARL logs only the Vl and policy keys (informarl.py:357-457)
             out.update({"Vh/loss_Vh": float(s[1, 0] / (R * nh)), "Vh/grad_Vh_norm": float(o["Vh"][4]),
                         "Vh/grad_Vh_has_nan": float(o["Vh"][5])})
         if self.algo in ("dgppo", "hcbfcrpo"):   # hcbfcrpo.py:204
-            out["eval/safe_data"] = float(s[3, 0] / (B * self.T * self.cfg.n_agents))
+            out["eval/safe_data"] = safe / (self.world * B * self.T * self.cfg.n_agents)
         return out

@@ -143,7 +143,11 @@ class MultiAgentEnv(ABC):
         agent = torch.empty(B, n, sd, device=dev)
         goal = torch.empty(B, cfg.n_goals, sd, device=dev)
         obst = torch.empty(B, cfg.n_obs, cfg.obst_stride, device=dev) if cfg.n_obs > 0 else None
-        OE.env_reset(cfg, seeds, agent, goal, obst)
+        n_failed = torch.zeros(1, dtype=torch.int32, device=dev)
+        OE.env_reset(cfg, seeds, agent, goal, obst, n_failed)
+        if int(n_failed.item()):       # the API path may sync: an invalid scene never leaves reset()
+            raise RuntimeError(f"env reset: {int(n_failed.item())} of {B} scenes could not be placed within the kernels' "
+                               f"rejection-loop bounds (too many agents / obstacles for the area?)")
         hits, g = None, None
         rc, rs = self._rays()
         if self._has_hits or want_graph:
@@ -213,8 +217,21 @@ class MultiAgentEnv(ABC):
         zero = torch.zeros(1, self.num_agents, 2, device=self.device)
         return self.step_batch(st, zero)[2][0]                # cost is a function of the pre-step graph only
 
-    def get_graph(self, env_state, lidar_data=None) -> GraphsTuple:
+    def _batch_of_env_state(self, env_state, lidar_data) -> BatchState:
         raise NotImplementedError
+
+    def get_graph(self, env_state, lidar_data=None) -> GraphsTuple:
+        """GraphsTuple of ONE environment state (dgppo/env/lidar_env/base.py:227-271 `get_graph(state, lidar_data)`,
+        dgppo/env/mpe/base.py:211-241 `get_graph(env_state)`): an adapter over the batched `graph_batch` (B = 1).  For a LiDAR
+        env with obstacles `lidar_data` are the top-k hit points, [n, k, 2] (or merged [n * k, 2]) as `get_lidar_vmap`
+        returns them; when omitted they are sensed from the state first."""
+        st = self._batch_of_env_state(env_state, lidar_data)
+        if self._has_hits and st.hits is None:
+            hits = torch.empty(1, self.num_agents, self.cfg.top_k, 2, device=self.device)
+            rc, rs = self._rays()
+            OE.env_step(self.cfg, st.agent, None, st.goal, st.obst, None, rc, rs, None, hits, None, None, None)
+            st = BatchState(st.agent, st.goal, st.obst, hits)
+        return self._squeeze(self.graph_batch(st))
 
     def render_video(self, rollout, video_path, Ta_is_unsafe=None, viz_opts: Optional[dict] = None, dpi: int = 100, **kwargs):
         """One episode as an animation (dgppo/env/lidar_env/base.py:209-221, dgppo/env/mpe/base.py render_video).  `rollout`

@@ -77,6 +77,18 @@ class _LidarEnv(MultiAgentEnv):
         return BatchState(agent, goal, obst, hits)
 
 
+    def _batch_of_env_state(self, env_state: LidarEnvState, lidar_data) -> BatchState:
+        n, ng, sd, dev = self.num_agents, self.cfg.n_goals, self.state_dim, self.device
+        f = lambda x, *shape: torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(*shape).contiguous()
+        obst = hits = None
+        if self.cfg.n_obs > 0:
+            obst = _records_from_rect(Rectangle(*[torch.as_tensor(v, dtype=torch.float32, device=dev)
+                                                  for v in env_state.obstacle])).reshape(1, self.cfg.n_obs, 16).contiguous()
+            if lidar_data is not None:
+                hits = f(lidar_data, 1, n, self.cfg.top_k, 2)
+        return BatchState(f(env_state.agent, 1, n, sd), f(env_state.goal, 1, ng, sd), obst, hits)
+
+
 class LidarSpread(_LidarEnv):
     KIND = "LidarSpread"
     PARAMS = dict(_LidarEnv.PARAMS)
@@ -108,6 +120,13 @@ class _MPE(MultiAgentEnv):
         goal = states[..., n:n + ng, :].reshape(1, ng, 4).contiguous()
         obst = states[..., n + ng:n + ng + self.cfg.n_obs, :].reshape(1, self.cfg.n_obs, 4).contiguous() if self.cfg.n_obs > 0 else None
         return BatchState(agent, goal, obst, None)
+
+
+    def _batch_of_env_state(self, env_state: MPEEnvState, lidar_data=None) -> BatchState:
+        n, ng, dev = self.num_agents, self.cfg.n_goals, self.device
+        f = lambda x, *shape: torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(*shape).contiguous()
+        obst = f(env_state.obs, 1, self.cfg.n_obs, 4) if self.cfg.n_obs > 0 else None
+        return BatchState(f(env_state.agent, 1, n, 4), f(env_state.goal, 1, ng, 4), obst, None)
 
 
 class MPESpread(_MPE):

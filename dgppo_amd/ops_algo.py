@@ -84,6 +84,23 @@ def lagr_update(lp_new, lp_old, Vh_mb, Ah_mb, lagr, sums, gamma: float, lr: floa
     N.check(rc, "dgppo_lagr_update")
 
 
+def lagr_sums(lp_new, lp_old, Vh_mb, Ah_mb, sums, gamma: float):
+    """first half of update_lagr for the data-parallel path: this rank's share of the sums (+=)"""
+    Eb, T, n, nh = Ah_mb.shape
+    N.expect_shape(lp_new, (Eb, T, n), "lp_new"); N.expect_shape(lp_old, (Eb, T, n), "lp_old")
+    N.expect_shape(Vh_mb, (Eb, T + 1, n, nh), "Vh"); N.expect_shape(sums, (n * nh,), "sums")
+    rc = N.lib().dgppo_lagr_sums(N.ptr(lp_new), N.ptr(lp_old), N.ptr(Vh_mb), C.c_int64((T + 1) * n * nh), N.ptr(Ah_mb),
+                                 N.ptr(sums), Eb, T, n, nh, C.c_float(1.0 - gamma), N.stream_ptr())
+    N.check(rc, "dgppo_lagr_sums")
+
+
+def lagr_apply(lagr, sums, rows_total: int, lr: float):
+    """second half: lagr = relu(lagr + lr * sums / rows_total); sums are zeroed.  rows_total = GLOBAL n_env * T."""
+    N.expect_shape(sums, (lagr.numel(),), "sums")
+    rc = N.lib().dgppo_lagr_apply(N.ptr(lagr), N.ptr(sums), lagr.numel(), C.c_int64(rows_total), C.c_float(lr), N.stream_ptr())
+    N.check(rc, "dgppo_lagr_apply")
+
+
 def relu_fwd(x, out):
     rc = N.lib().dgppo_relu_fwd(N.ptr(x), N.ptr(out), C.c_int64(x.numel()), N.stream_ptr())
     N.check(rc, "dgppo_relu_fwd")

@@ -103,16 +103,31 @@ def graph_materialize(cfg: N.EnvCfg, agent, goal, obst, hits, graph: Dict[str, t
     N.check(rc, "dgppo_graph_materialize")
 
 
-def env_reset(cfg: N.EnvCfg, seeds: torch.Tensor, agent, goal, obst):
+def env_reset(cfg: N.EnvCfg, seeds: torch.Tensor, agent, goal, obst, n_failed: torch.Tensor = None):
+    """n_failed: optional int32 device counter (caller-zeroed), += 1 per env whose bounded rejection loops ran out — read it at
+    the next host sync and do not use the batch when it is non-zero (dgppo_env_reset_checked)."""
     B = seeds.shape[0]
     n, sd = cfg.n_agents, cfg.state_dim
     N.expect_shape(agent, (B, n, sd), "agent")
     N.expect_shape(goal, (B, cfg.n_goals, sd), "goal")
     if cfg.n_obs > 0:
         N.expect_shape(obst, (B, cfg.n_obs, cfg.obst_stride), "obst")
-    rc = N.lib().dgppo_env_reset(C.byref(cfg), N.ptr(seeds, torch.int64, "seeds"), N.ptr(agent, name="agent"),
-                                 N.ptr(goal, name="goal"), N.ptr(obst, name="obst"), C.c_int32(B), N.stream_ptr())
+    if n_failed is not None:
+        N.expect_shape(n_failed, (1,), "n_failed")
+    rc = N.lib().dgppo_env_reset_checked(C.byref(cfg), N.ptr(seeds, torch.int64, "seeds"), N.ptr(agent, name="agent"),
+                                         N.ptr(goal, name="goal"), N.ptr(obst, name="obst"),
+                                         N.ptr(n_failed, torch.int32, "n_failed"), C.c_int32(B), N.stream_ptr())
     N.check(rc, "dgppo_env_reset")
+
+
+def randn_rows(seed: int, out: torch.Tensor, global_row_len: int, col_offset: int):
+    """out [rows, row_len] = the column window [col_offset, col_offset + row_len) of randn(seed) viewed as rows of
+    global_row_len (data-parallel rollouts: a rank's share of the global noise)."""
+    rows = int(out.shape[0])
+    row_len = out.numel() // max(rows, 1)
+    rc = N.lib().dgppo_randn_rows(C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), N.ptr(out, name="out"), C.c_int64(rows),
+                                  C.c_int64(row_len), C.c_int64(global_row_len), C.c_int64(col_offset), N.stream_ptr())
+    N.check(rc, "dgppo_randn_rows")
 
 
 def randn(seed: int, offset: int, out: torch.Tensor):

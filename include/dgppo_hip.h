@@ -159,10 +159,24 @@ int32_t dgppo_graph_materialize(const dgppo_env_cfg* cfg,
  *   seeds [B] uint64;  out: agent [B,n,sd], goal [B,ng,sd], obst (layout as above).      */
 int32_t dgppo_env_reset(const dgppo_env_cfg* cfg, const uint64_t* seeds,
                         float* agent, float* goal, float* obst, int32_t B, void* stream);
+/* The same with a failure counter.  The reference's rejection loops (env/utils.py:139-244 `while_loop`s, mpe_connect_spread.py
+ * :50-107) are unbounded; the kernels bound every loop so that all threads finish, and an env whose bound ran out holds an
+ * INVALID scene.  *n_failed (DEVICE int32, caller-zeroed, may be NULL) is incremented once per such env; the caller reads it
+ * at its next host sync and must not train on the batch when it is non-zero.  Both entry points also reject, on the host
+ * and before launching, densities at which the placement cannot succeed (negative return).                              */
+int32_t dgppo_env_reset_checked(const dgppo_env_cfg* cfg, const uint64_t* seeds, float* agent, float* goal, float* obst,
+                                int32_t* n_failed, int32_t B, void* stream);
 
 /* Standard-normal noise: Philox-4x32-10 + Box-Muller, out[i] for i<n_elem; replaces the
  * jax.random draw inside dist.sample(seed=key) (algo/module/policy.py:196-203).         */
 int32_t dgppo_randn(uint64_t seed, uint64_t offset, float* out, int64_t n_elem, void* stream);
+/* A column window of the same stream laid out as rows: out[r, c] (dense [rows, row_len]) = element r * global_row_len +
+ * col_offset + c of dgppo_randn(seed, 0, ...).  Data-parallel rollouts: the sampling noise of step t is a row of
+ * global_row_len = world * B_local * n * 2 normals and a rank fills the window of its envs, so that the union of the ranks'
+ * rollouts is the single-device rollout of the global batch (jax.random.split(key, B) of dgppo/algo/informarl.py:254-256 is
+ * likewise a function of the global env index).                                                                          */
+int32_t dgppo_randn_rows(uint64_t seed, float* out, int64_t rows, int64_t row_len, int64_t global_row_len,
+                         int64_t col_offset, void* stream);
 
 /* ---- networks: building blocks ------------------------------------------------------------ */
 /* All matrices row-major fp32; `ld*` = leading dimension in floats.                              */
@@ -321,6 +335,12 @@ int32_t dgppo_advantage_lagr(const float* Ql, const float* Vl, const float* Qh, 
 int32_t dgppo_lagr_update(const float* lp_new, const float* lp_old, const float* Vh, int64_t vh_env_stride,
                           const float* Ah, float* lagr, float* sums, int32_t n_env, int32_t T, int32_t n, int32_t nh,
                           float one_minus_gamma, float lr, void* stream);
+/* The same step in two halves for the data-parallel update (the `.mean()` of informarl_lagr.py:300-304 runs over the GLOBAL
+ * minibatch): dgppo_lagr_sums accumulates this rank's share into sums[n*nh] (+=), the caller all-reduces sums, and
+ * dgppo_lagr_apply does lagr = relu(lagr + lr * sums / rows_total) with rows_total = global n_env * T, then zeroes sums. */
+int32_t dgppo_lagr_sums(const float* lp_new, const float* lp_old, const float* Vh, int64_t vh_env_stride, const float* Ah,
+                        float* sums, int32_t n_env, int32_t T, int32_t n, int32_t nh, float one_minus_gamma, void* stream);
+int32_t dgppo_lagr_apply(float* lagr, float* sums, int32_t count, int64_t rows_total, float lr, void* stream);
 /* out = max(x, 0): jnp.clip(rollout.costs, a_min=0) of informarl_lagr.py:213                                             */
 int32_t dgppo_relu_fwd(const float* x, float* out, int64_t count, void* stream);
 /* InforMARL's stage cost l = -reward + w * sum_{agents, components} max(cost, 0) (dgppo/algo/informarl.py:329), as the

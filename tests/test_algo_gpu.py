@@ -39,6 +39,41 @@ def test_gae(cuda, monkeypatch, B, T, n, nh, lam):
     np.testing.assert_allclose(outs["cols"][1], outs["rows"][1], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("family", ["cols", "rows", "generic"])
+def test_gae_propagates_nan_like_the_reference(cuda, monkeypatch, family):
+    """jnp.maximum / .max(-1) propagate NaN (algo/utils.py:39-44) and `mask * NaN` is NaN; v_max_f32 drops a NaN operand.
+    A NaN cost (a NaN LiDAR hit point reaches get_cost), a NaN reward and a NaN value must mark exactly the entries the
+    oracle marks: Qh[t' <= t, agent, all components] for a cost, Ql[t' <= t] for a reward, t' < t for an inserted value —
+    and nothing else.  All three kernel families (column-parallel default, row-parallel, generic)."""
+    from dgppo_amd import ops_algo as O
+    B, T, n, nh = 6, (300 if family == "generic" else 40), 3, 2
+    lam = 0.95
+    if family == "rows":
+        monkeypatch.setenv("DGPPO_GAE_ROWS", "1")
+    r = np.random.default_rng(3)
+    costs = r.uniform(-1, 1, size=(B, T, n, nh)).astype(np.float32)
+    rew = (-r.uniform(0, 0.02, size=(B, T))).astype(np.float32)
+    Vh = r.uniform(-1, 1, size=(B, T + 1, n, nh)).astype(np.float32)
+    Vl = r.uniform(0, 1, size=(B, T + 1)).astype(np.float32)
+    costs[0, 25, 1, 0] = np.nan                       # one component of one agent in the middle
+    costs[1, T - 1, 2, 1] = np.nan                    # last step: every Qh of that agent
+    costs[2, 0, 0, 1] = np.nan                        # first step: only Qh[0]
+    rew[3, 17] = np.nan                               # the cost-value column
+    Vh[4, 30, 1, 1] = np.nan                          # an inserted value row: t' < 30 of that (agent, component) only
+    Qh_w, Ql_w = A.gae_batch(costs, rew, Vh, Vl, 0.99, lam)
+    assert np.isnan(Qh_w[0, :26, 1, :]).all() and not np.isnan(Qh_w[0, 26:]).any() and not np.isnan(Qh_w[0, :, [0, 2]]).any()
+    assert np.isnan(Qh_w[4, :30, 1, 1]).all() and not np.isnan(Qh_w[4, 30:, 1, 1]).any() and not np.isnan(Qh_w[4, :, 1, 0]).any()
+    assert np.isnan(Ql_w[3, :18]).all() and not np.isnan(Ql_w[3, 18:]).any() and not np.isnan(Qh_w[3]).any()
+    d = lambda x: torch.from_numpy(x).to(cuda)
+    Qh = torch.zeros(B, T, n, nh, device=cuda); Ql = torch.zeros(B, T, device=cuda)
+    O.gae(d(costs), d(rew), d(Vh), d(Vl), O.lam_pow_table(lam, T, cuda), 0.99, lam, Qh, Ql)
+    Qh, Ql = Qh.cpu().numpy(), Ql.cpu().numpy()
+    assert np.array_equal(np.isnan(Qh), np.isnan(Qh_w)), "NaN pattern of Qh differs from the oracle's"
+    assert np.array_equal(np.isnan(Ql), np.isnan(Ql_w)), "NaN pattern of Ql differs from the oracle's"
+    np.testing.assert_allclose(np.nan_to_num(Qh), np.nan_to_num(Qh_w), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(np.nan_to_num(Ql), np.nan_to_num(Ql_w), rtol=0, atol=1e-5)
+
+
 def test_advantage(cuda):
     from dgppo_amd import ops_algo as O
     r = np.random.default_rng(5)

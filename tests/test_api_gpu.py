@@ -60,6 +60,18 @@ def test_single_graph_env_api_matches_oracle(cuda, env_id, n, obs):
     np.testing.assert_allclose(_np(res.graph.edges), want["graph"]["edges"][0], atol=1e-6)
     np.testing.assert_allclose(_np(env.get_cost(g)), want["cost"][0], atol=1e-6)
     assert not bool(res.done) and res.info == {}
+    # env.get_graph(env_state[, lidar_data]) (lidar_env/base.py:227, mpe/base.py:211): rebuilds the same GraphsTuple from the
+    # env state, with the hit points handed in and with the hit points sensed from the state
+    es = res.graph.env_states
+    variants = [env.get_graph(es)]
+    if ocfg.is_lidar and obs > 0:
+        k = 8
+        lidar = res.graph.type_states(2, n * k)[:, :2]
+        variants += [env.get_graph(es, lidar.reshape(n, k, 2)), env.get_graph(es, lidar)]
+    for g2 in variants:
+        for f in ("nodes", "edges", "states", "receivers", "senders", "node_type"):
+            assert torch.equal(getattr(g2, f), getattr(res.graph, f)), f
+        assert int(g2.n_node) == N_ and int(g2.n_edge) == E_
 
 
 def _mk_algo(env, batch_size, seed=0, train_steps=100):

@@ -390,40 +390,121 @@ def test_full_topology_multi_block_prepass_targets_and_gradients(cuda, kind, n, 
     assert info["Vl/has_nan"] == 0.0 and float(eng.opt["policy"].state[2]) == B // Eb
 
 
-def test_two_rank_update_allreduce_equals_full_minibatch(cuda, tmp_path):
-    """Engine(allreduce=..., world=2) as bench.py / train.py drive it, two ranks sharing this GPU over gloo
-    (tools/dist_rehearsal.py): the ONE all-reduced flat buffer [g_policy | g_Vl | g_Vh | loss sums] / world must equal
-    the single-process gradient on the union minibatch (mean of equal shards = global mean), the logged
-    losses must be the global means, and both replicas must hold bit-identical parameters after all optimiser steps."""
-    import socket
-    import subprocess
-    import sys as _sys
-    sys_path = os.path.join(ROOT, "tools", "dist_rehearsal.py")
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
-    procs = [subprocess.Popen([_sys.executable, sys_path, "--rank", str(r), "--world", "2", "--port", str(port), "--out", outs[r]],
-                              cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
-    res = [torch.load(o, weights_only=True) for o in outs]
-    # single process, the same four envs, minibatch = all of them (batch_size x world)
+def test_nan_cost_skips_exactly_the_poisoned_minibatch(cuda):
+    """A NaN cost in the deterministic rollout (a NaN LiDAR hit point reaches get_cost) must do what it does in the reference:
+    the Dec-OCP targets of that env turn NaN (jnp.maximum propagates), the Vh loss and gradient of the minibatch holding
+    the env are NaN, `has_any_nan_or_inf` fires and optax.apply_if_finite leaves the parameters and the Adam state alone —
+    while the other minibatch, and the other two networks, train normally (dgppo.py:296-321, trainer/utils.py:109-118)."""
+    B, T_, rs, bs = 4, 8, 4, 16
+    cfg, ocfg, hp, eng, trees = _setup("LidarSpread", 3, 2, B, T_, cuda, bs, rs)
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
+    ro = eng.rollout(seeds, True, noise_seed=3)
+    det = eng.rollout(seeds + 1000, False)
+    det.cost_tm[5, 3, 1, 0] = float("nan")                    # env 3, step 5, agent 1
+    snap = {}
+
+    def hook(name, net, mb):
+        if name == "Vh":
+            snap[mb] = (net.params.detach().clone(), eng.opt["Vh"].state[:8].detach().clone())
+    eng.grad_hook = hook
+    before = {k: net.params.detach().clone() for k, net in eng.nets.items()}
+    info = eng.update(ro, det, 10, np.asarray([0, 1, 2, 3]))  # minibatch 1 = envs {2, 3}
+    torch.cuda.synchronize()
+    Qh_det = eng.arena.get("tg.Qh_det", B, T_, cfg.n_agents, 2)
+    assert torch.isnan(Qh_det[3, :6, 1, :]).all() and not torch.isnan(Qh_det[3, 6:]).any() and not torch.isnan(Qh_det[:3]).any()
+    assert info["Vh/grad_Vh_has_nan"] == 1.0 and info["Vl/has_nan"] == 0.0 and info["policy/has_nan"] == 0.0
+    assert torch.equal(snap[0][0], before["Vh"])               # minibatch 0 is entered with the initial parameters
+    assert not torch.equal(snap[1][0], before["Vh"]), "minibatch 0 (clean) did not train Vh"
+    assert torch.equal(eng.Vh.params, snap[1][0]), "the poisoned minibatch changed the Vh parameters"
+    assert float(eng.opt["Vh"].state[2]) == float(snap[1][1][2]) == 1.0, "Adam count moved on a skipped step"
+    assert torch.isfinite(eng.Vh.params).all() and torch.isfinite(eng.opt["Vh"].m).all()
+    for k in ("policy", "Vl"):
+        assert float(eng.opt[k].state[2]) == 2.0 and torch.isfinite(eng.nets[k].params).all()
+
+
+def _two_ranks(mode, tmp_path):
+    """tools/dist_rehearsal.py as two supervised ranks sharing this GPU over gloo (dgppo_amd/launch.py: per-rank log files —
+    no pipe can fill up — and the job stops as soon as one rank fails) -> the two ranks' result files"""
+    import io
+    from dgppo_amd import launch
+    prefix = str(tmp_path / mode)
+    out, err = io.StringIO(), io.StringIO()
+    rc = launch.spawn_ranks(os.path.join(ROOT, "tools", "dist_rehearsal.py"), ["--mode", mode, "--out", prefix], 2,
+                            str(tmp_path / "ranklogs"), stall_seconds=300, out=out, err=err)
+    assert rc == 0, err.getvalue()[-6000:]
+    return [torch.load(f"{prefix}.r{r}.pt", weights_only=True) for r in range(2)]
+
+
+def _twin(mode, cuda, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import dist_rehearsal as DR
-    eng = DR.build_engine(cuda, 1, None, shard_envs=4)
-    g1, p1, info1 = DR.run(eng, cuda, 4, [0, 1, 2, 3])
+    return DR.run_mode(mode, cuda, 1, 0, None, 2, log_dir=str(tmp_path / "twin_logs"))
+
+
+def _assert_params_follow(res, twin, tol, label):
+    for it, (p0, p1, pt) in enumerate(zip(res[0]["params"], res[1]["params"], twin["params"])):
+        for name in p0:
+            assert torch.equal(p0[name], p1[name]), f"{label}: replicas diverged in {name} after iteration {it}"
+            scale = float(pt[name].abs().max())
+            err = float((p0[name] - pt[name]).abs().max())
+            assert err <= tol * scale, f"{label}: {name} after iteration {it}: {err:.3e} from the single-process run (scale {scale:.3g})"
+
+
+def test_two_rank_update_allreduce_equals_full_minibatch(cuda, tmp_path):
+    """Engine(allreduce=..., world=2, rank=r) with the real sharding (rank r owns the global envs [4r, 4r+4): seeds and
+    sampling noise are functions of the global env index), two ranks sharing this GPU over gloo: the ONE all-reduced flat
+    buffer [g_policy | g_Vl | g_Vh | loss sums] / world must equal the single-process gradient on the union minibatch
+    (mean of equal shards = global mean), the logged scalars must be global and equal the single-process
+    ones, and both replicas must hold bit-identical parameters after all optimiser steps."""
+    res = _two_ranks("eager", tmp_path)
+    twin = _twin("eager", cuda, tmp_path)
     for name in ("policy", "Vl", "Vh"):
         assert torch.equal(res[0]["grads"][name], res[1]["grads"][name]), f"{name}: ranks disagree on the reduced gradient"
-        assert torch.equal(res[0]["params"][name], res[1]["params"][name]), f"{name}: replicas diverged"
         got = res[0]["grads"][name] / 2.0
-        scale = float(g1[name].abs().max())
-        err = float((got - g1[name]).abs().max())
+        scale = float(twin["grads"][name].abs().max())
+        err = float((got - twin["grads"][name]).abs().max())
         assert err <= 2e-5 * max(scale, 1e-3), f"{name}: all-reduced mean gradient off by {err:.3e} (scale {scale:.3e})"
-    for k in ("Vl/loss", "Vh/loss_Vh", "policy/loss", "policy/entropy"):
-        assert abs(res[0]["info"][k] - res[1]["info"][k]) < 1e-7
-    # 2 ranks x 2 minibatches of 2 envs walk the same global minibatches as 1 process x 1 minibatch only at step 0:
-    # compare the FIRST step's logged quantities through a one-minibatch single-process run is not possible after two
-    # optimiser steps, so the loss check is on the replicas' agreement above and on finiteness here
-    assert all(np.isfinite(v) for v in res[0]["info"].values())
+    _assert_params_follow(res, twin, 2e-5, "eager")
+    i0, i1, it = res[0]["info"][0], res[1]["info"][0], twin["info"][0]
+    for k in it:                                   # every logged value is global: identical on the ranks, equal to the twin's
+        assert i0[k] == i1[k], f"{k}: rank 0 logs {i0[k]!r}, rank 1 {i1[k]!r}"
+        assert abs(i0[k] - it[k]) <= 2e-5 * max(1.0, abs(it[k])), f"{k}: {i0[k]!r} vs single-process {it[k]!r}"
+
+
+def test_two_rank_graph_replay_path_keeps_replicas_identical_and_follows_the_single_process_run(cuda, tmp_path):
+    """The path bench.py and the algos really run under data parallelism: graph(body_pre) -> eager all-reduce ->
+    graph(optimiser steps), use_graphs=True, no gradient hook, THREE iterations so that iterations 2 and 3 replay both
+    graphs with fresh rollouts in the persistent buffers (stale pointers or an ordering bug between the two
+    replays and the collective would show as diverging replicas or as drift from the single-process run)."""
+    res = _two_ranks("graphs", tmp_path)
+    twin = _twin("graphs", cuda, tmp_path)
+    _assert_params_follow(res, twin, 5e-5, "graphs")
+    for it in range(3):
+        for k in ("Vl/loss", "Vh/loss_Vh", "policy/loss", "eval/safe_data"):
+            assert res[0]["info"][it][k] == res[1]["info"][it][k]
+            assert abs(res[0]["info"][it][k] - twin["info"][it][k]) <= 5e-5 * max(1.0, abs(twin["info"][it][k])), (it, k)
+
+
+def test_two_rank_trainer_is_the_single_process_trainer_on_the_union_batch(cuda, tmp_path):
+    """train.py's wiring (make_env / make_algo(allreduce, world, rank) / Trainer(rank, world).train()) for two iterations as two
+    gloo ranks on this GPU: bit-identical parameters on the ranks, equal to the one-rank Trainer on the union batch (global
+    n_env_train = 8, global minibatch = 4 envs), and only rank 0 evaluates, logs and saves."""
+    res = _two_ranks("trainer", tmp_path)
+    twin = _twin("trainer", cuda, tmp_path)
+    _assert_params_follow(res, twin, 5e-5, "trainer")
+    assert res[0]["wrote_logs"] and res[0]["saved_models"] == ["0", "1"]
+    assert not res[1]["wrote_logs"] and res[1]["saved_models"] == []
+
+
+def test_two_rank_informarl_lagr_all_reduces_the_multiplier_step(cuda, tmp_path):
+    """informarl_lagr under data parallelism: the `.mean()` of the multiplier step (informarl_lagr.py:300-306) runs over the
+    global minibatch — per-rank sums, one more small all-reduce, identical step on every rank."""
+    res = _two_ranks("lagr", tmp_path)
+    twin = _twin("lagr", cuda, tmp_path)
+    _assert_params_follow(res, twin, 5e-5, "lagr")
+    assert torch.equal(res[0]["lagr"], res[1]["lagr"])
+    assert float((res[0]["lagr"] - twin["lagr"]).abs().max()) <= 1e-5 * float(twin["lagr"].abs().max())
+    assert float((twin["lagr"] - 0.78).abs().max()) > 1e-6, "the multipliers did not move: the check would be vacuous"
 
 
 @pytest.mark.parametrize("algo", ["dgppo", "informarl"])

@@ -168,6 +168,30 @@ def test_reset_matches_oracle_stream(cuda, kind, n, n_obs):
             np.testing.assert_array_equal(go, wo)
 
 
+def test_reset_reports_scenes_it_could_not_place(cuda):
+    """The reference's rejection loops are unbounded; the kernels bound them.  (1) A density at which placement cannot succeed is
+    refused on the host before anything is launched.  (2) A config that passes that test but still cannot be placed — here
+    obstacles cover the whole area — finishes (every loop is bounded) and says so: the failure counter equals the number
+    of invalid scenes, and the API-level reset raises instead of handing out a colliding scene.  (3) The benchmark
+    configs leave the counter at zero."""
+    from dgppo_amd import _native as N, ops_env as O
+    crowded = N.make_env_cfg(N.ENV_KINDS["MPESpread"], 16, 0, area_size=0.3)
+    seeds = torch.arange(1, 9, dtype=torch.int64, device=cuda)
+    with pytest.raises(ValueError, match="cannot be placed"):
+        O.env_reset(crowded, seeds, torch.empty(8, 16, 4, device=cuda), torch.empty(8, 16, 4, device=cuda), None)
+    walled = N.make_env_cfg(N.ENV_KINDS["LidarSpread"], 2, 48, area_size=0.4)
+    nf = torch.zeros(1, dtype=torch.int32, device=cuda)
+    O.env_reset(walled, seeds, torch.empty(8, 2, 4, device=cuda), torch.empty(8, 2, 4, device=cuda),
+                torch.empty(8, 48, 16, device=cuda), nf)
+    assert int(nf.item()) == 8
+    cfg, _ = _mk("LidarSpread", 8, 3)
+    nf.zero_()
+    big = torch.arange(1, 4097, dtype=torch.int64, device=cuda) * 7919
+    O.env_reset(cfg, big, torch.empty(4096, 8, 4, device=cuda), torch.empty(4096, 8, 4, device=cuda),
+                torch.empty(4096, 3, 16, device=cuda), nf)
+    assert int(nf.item()) == 0
+
+
 def test_full_size_rollout_properties(cuda):
     """BASELINE config 3 at full size (4096 envs): 3 chained steps on the device vs the oracle, every output, bit-exact."""
     from dgppo_amd import ops_env as O
@@ -197,6 +221,24 @@ def test_full_size_rollout_properties(cuda):
     assert np.all(g["n_node"] == 81) and np.all(g["n_edge"] == 192)
     assert np.all((g["receivers"] == 80) == (g["senders"] == 80))
     assert np.all(g["states"][:, 80] == -1)
+
+
+def test_randn_rows_is_a_column_window_of_the_flat_stream(cuda):
+    """dgppo_randn_rows: out[r, c] = element r * global_row_len + col_offset + c of dgppo_randn(seed, 0) — every alignment of
+    the window against the 4-wide Philox blocks, the full row (== the flat stream), and the union of two ranks' windows."""
+    from dgppo_amd import ops_env as O
+    rows, L = 5, 38                                    # 38 % 4 != 0: rows start at every phase of a Philox block
+    flat = torch.empty(rows * L, device=cuda)
+    O.randn(99, 0, flat)
+    full = torch.empty(rows, L, device=cuda)
+    O.randn_rows(99, full, L, 0)
+    assert torch.equal(full.view(-1), flat)
+    for off, ln in ((0, 19), (19, 19), (1, 4), (3, 1), (7, 30), (37, 1), (6, 0)):
+        w = torch.full((rows, ln), float("nan"), device=cuda)
+        O.randn_rows(99, w, L, off)
+        assert torch.equal(w, flat.view(rows, L)[:, off:off + ln]), (off, ln)
+    with pytest.raises(ValueError):
+        O.randn_rows(99, torch.empty(rows, 10, device=cuda), L, 30)     # window runs past the row
 
 
 def test_randn_moments_and_determinism(cuda):
