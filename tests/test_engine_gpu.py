@@ -332,11 +332,16 @@ def test_hcbfcrpo_targets_and_gradients(cuda, kind, n, n_obs):
     assert "eval/safe_data" in info and "Vh/loss_Vh" not in info and abs(info["eval/safe_data"] - wt["safe"]) < 0.05
 
 
-@pytest.mark.parametrize("kind,n,n_obs,B,T_,rs", [
-    ("LidarSpread", 8, 3, 8, 8, 4),            # BASELINE config 3/4 topology: N = 81 nodes, fan-in 24
-    ("LidarBicycleTarget", 16, 8, 5, 4, 2),    # BASELINE config 5 topology: N = 161 nodes, state_dim 5, node_dim 8
+@pytest.mark.parametrize("kind,n,n_obs,B,T_,rs,blk", [
+    ("LidarSpread", 8, 3, 8, 8, 4, 3),            # BASELINE config 3/4 topology: N = 81 nodes, fan-in 24
+    ("LidarBicycleTarget", 16, 8, 5, 4, 2, 3),    # BASELINE config 5 topology: N = 161 nodes, state_dim 5, node_dim 8
+    # the benchmark's HORIZON: T = 128, rnn_step = 16 -> 8 chunks per env (rnn_chunk_ids (8, 16),
+    # dgppo.py:157-158), the [B, 129, ...] carry / value buffers, the env-major transpose of 129-step records, the
+    # gae_cols_kernel<32, 4> instantiation inside the engine, 129-graph pre-pass blocks
+    ("LidarSpread", 8, 3, 8, 128, 16, 3),
+    ("LidarBicycleTarget", 16, 8, 3, 128, 16, 2),
 ])
-def test_full_topology_multi_block_prepass_targets_and_gradients(cuda, kind, n, n_obs, B, T_, rs):
+def test_full_topology_multi_block_prepass_targets_and_gradients(cuda, kind, n, n_obs, B, T_, rs, blk):
     """The engine exactly as training / bench.py runs it (HIP-graph rollouts, three-stream update) at the benchmark
     TOPOLOGIES, with the value pre-passes forced into >= 3 env blocks with a ragged last one (`prepass_graphs`): at
     B = 4096, T = 128 the default blocking is 9 blocks of 508 envs, so the e0 > 0 slices / strided bases of
@@ -344,10 +349,10 @@ def test_full_topology_multi_block_prepass_targets_and_gradients(cuda, kind, n, 
     Vl / Vh / Vh_det / Ql / Qh / Qh_det and the first minibatch's gradients against the oracle (dgppo.py:204-229,
     296-321; informarl.py:357-457), plus: the blocked result equals the single-block result (1e-6)."""
     bs = 2 * T_ if B % 2 == 0 else T_                                       # envs per minibatch: 2 (or 1 when B is odd)
-    kw = dict(prepass_graphs=3 * (T_ + 1) + 1, use_graphs=True, multi_stream=True)
+    kw = dict(prepass_graphs=blk * (T_ + 1) + 1, use_graphs=True, multi_stream=True)
     cfg, ocfg, hp, eng, trees = _setup(kind, n, n_obs, B, T_, cuda, bs, rs, **kw)
     block = eng.prepass_graphs // (T_ + 1)
-    assert block == 3 and B % block != 0 and -(-B // block) >= 2, "needs a ragged multi-block split"
+    assert block == blk and B % block != 0 and -(-B // block) >= 2, "needs a ragged multi-block split"
     seeds = torch.arange(1, B + 1, dtype=torch.int64, device=cuda) * 7919
     # two calls each: the second one replays the captured HIP graph (the path training uses)
     for _ in range(2):
