@@ -14,7 +14,11 @@
 //   * every size is a template parameter: all loops unroll, index divisions fold, no dynamic-trip-count loop scaffolding;
 //   * the constant parts of the node / state rows (indicator columns, zero padding, the pad row) are written into the
 //     wave's LDS image ONCE; per env only agent / goal states and hit points are patched in, then the image is streamed out;
-//   * segment tests of an obstacle are SKIPPED for a pair of agents when both are provably out of its reach (see "cull");
+//   * segment tests are run on a COMPACTED candidate list: an (agent, obstacle) pair that is provably out of reach, and a ray
+//     whose line provably misses the obstacle's bounding circle, can have no accepted segment (see "cull"); the surviving
+//     (agent, obstacle, ray) triples — ~60 of 768 per env — are appended to a list in LDS (ballot + mbcnt) and processed 64
+//     per pass, four segments each; results meet in a per-(agent, ray) LDS word through ds_min_u32 (alphas are >= +0, so
+//     their bit patterns order like the floats);
 //   * stable top-k straight from registers: ranks of the (many) missing rays by popcount of ballots, ranks of the (few)
 //     hitting rays by a wave-uniform loop over the hitting lanes — no 32-key compare ladder, no keys in LDS;
 //   * per-agent minima (cost, goal distances) by DPP row reductions instead of serial LDS loops.
@@ -30,6 +34,12 @@
 // So no segment of a culled obstacle can be valid for either agent of the pair, det cannot be 0 or NaN there (NaN inputs
 // fail the distance comparison and are never culled), and skipping the obstacle leaves alpha unchanged.  Obstacles whose
 // edges are nearly parallel to a ray of the fan (about 1 in 70) are simply never culled.
+// Ray-level cull, same argument: for such a "robust" obstacle an accepted (alpha, beta) has beta within 4e-3 of the exact
+// parameter of the intersection X of the ray's LINE with the edge's line, so X lies within 4e-3 |e| < 2e-3 of the edge, i.e.
+// within h_o + 2e-3 of c_o; and alpha within 4e-3 puts X no farther than 0.002 R behind p along the ray direction d.  Hence
+// if the line misses the circle (c_o, h_o + 0.05) — |d x (c_o - p)| > h_o + 0.05 — or the circle lies wholly behind the
+// ray origin — d . (c_o - p) < -(h_o + 0.05) — no segment of o is valid for this ray (both tests are evaluated in fp32
+// with errors < 1e-6 against a slack of 0.048; a NaN fails both comparisons and keeps the triple).
 #include "env_step.h"
 #include <stdlib.h>
 
@@ -55,6 +65,10 @@ __device__ unsigned long long g_wstamps[64];
 __device__ unsigned long long g_wspan[3 * 8192];   // per wave: kernel entry, first env start, last env end (s_memtime)
 #define PHASE(name, idx) do { asm volatile("; PHASE " name ::: "memory"); \
     if (blockIdx.x == 0 && threadIdx.x == 0 && stamp_on) g_wstamps[idx] = __builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(DGPPO_PHASE_MARKS)
+// tools/isa_hist.py: assembler comments only (volatile keeps them ordered against the WSYNC fences; without a "memory"
+// clobber they do not fence the scheduler themselves, so the instruction stream is the production one up to placement)
+#define PHASE(name, idx) asm volatile("; PHASE " name)
 #else
 #define PHASE(name, idx) do { } while (0)    // (a marker with a "memory" clobber would also fence the scheduler)
 #endif
@@ -82,8 +96,12 @@ template <int SD, bool SPREAD, int NA, int NO>
 struct alignas(16) WaveLds {
   using C = WC<SD, SPREAD, NA, NO>;
   float4 seg[NO * 4];                 // per segment: x3, y3, ex = x4 - x3, ey = y4 - y3
-  float4 as[NA * NO * 4];             // per (agent, segment): ax = x1 - x3, ay = y1 - y3, na = ey ax - ex ay
-  float4 circ[NO];                    // cull circle: cx, cy, (R + h + 0.05)^2
+  float4 pc[NA * NO];                 // per (agent, obstacle): c_o - p, ray-cull threshold h_o + 0.05 (-1: pair out of reach, +inf: never cull)
+  float4 circ[NO];                    // cull circle: cx, cy, (R + h + 0.05)^2, h + 0.05
+  uint32_t alpha[NA * 32];            // per (agent, ray): bits of min alpha over the tested segments (1e6: no hit)
+  uint32_t badm[ceil4(NA)];           // per agent: rays that met det == 0 / NaN (literal re-evaluation)
+  float rayt[64];                     // ray fan: cos, sin per ray (once per wave)
+  uint16_t items[NA * NO * 32];       // candidate (agent, obstacle, ray) triples: (agent * NO + obstacle) << 5 | ray
   float next[ceil4(NA * SD)];         // state at t+1
   // inputs of the env, staged with ONE 16-byte load per lane: consecutive float4 items agent | goal | obst | hits | act
   float agent[NA * SD];               // state at t
@@ -196,7 +214,8 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
     }
   }
   // ---- once per wave: the constant part of the node / state images (lidar_env/base.py:236-264, graph.py:214-218) ----
-  for (int i = lane; i < ceil4(N * ND); i += 64) L.nodes[i] = 0.0f;
+  for (int i = lane; i < ceil4(N * ND) / 4; i += 64) reinterpret_cast<float4*>(L.nodes)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (do_sense) L.rayt[lane] = (lane & 1) ? a.ray_sin[lane >> 1] : a.ray_cos[lane >> 1];
   WSYNC();
   for (int node = lane; node < PAD; node += 64)
     L.nodes[node * ND + ((node < NA) ? SD + 2 : ((node < 2 * NA) ? SD + 1 : SD))] = 1.0f;
@@ -276,8 +295,8 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
           const float dx = P[2 * m] - cx, dy = P[2 * m + 1] - cy;
           h2 = fmaxf(h2, dx * dx + dy * dy);
         }
-        const float thr = sr + sqrtf(h2) + 0.05f;
-        L.circ[lane] = make_float4(cx, cy, thr * thr, 0.0f);
+        const float hm = sqrtf(h2) + 0.05f, thr = sr + hm;
+        L.circ[lane] = make_float4(cx, cy, thr * thr, hm);
       }
 #pragma unroll
       for (int o = 0; o < NO; ++o) {               // lanes: edge direction m = lane >> 5 (0, 1), ray = lane & 31
@@ -304,19 +323,12 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
           L.ino[q] = rect_inside_r0(L.obst + o * 16, px, py) ? 1.0f : 0.0f;
           const float4 cc = L.circ[o];
           const float dx = px - cc.x, dy = py - cc.y;
-          isfar = (dx * dx + dy * dy > cc.z) && ((robust_bits >> o) & 1u);
+          const bool robust = (robust_bits >> o) & 1u;
+          isfar = (dx * dx + dy * dy > cc.z) && robust;
+          // ray-level cull threshold of this pair: out of reach -> every ray is culled; non-robust obstacle -> none is
+          L.pc[q] = make_float4(cc.x - px, cc.y - py, isfar ? -1.0f : (robust ? cc.w : __builtin_inff()), 0.0f);
         }
         far[w] = __builtin_amdgcn_ballot_w64(isfar);
-      }
-#pragma unroll
-      for (int q0 = 0; q0 < NA * NO * 4; q0 += 64) {   // ray-independent part of the segment test
-        const int q = q0 + lane;
-        if (q < NA * NO * 4) {
-          const int i = q / (NO * 4), sgi = q - i * (NO * 4);
-          const float4 sg = L.seg[sgi];
-          const float ax = L.next[i * SD] - sg.x, ay = L.next[i * SD + 1] - sg.y;
-          L.as[q] = make_float4(ax, ay, sg.w * ax - sg.z * ay, 0.0f);
-        }
       }
     } else {
 #pragma unroll
@@ -465,45 +477,71 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
       if (lane == 0) { a.g.n_node[b] = N; a.g.n_edge[b] = E; }
     }
     PHASE("P2_rays", 5);
-    // ---- P2 + P3: per wave iteration, two agents x 32 rays: segment tests (obstacle.py:97-105) -> alpha -> stable
-    //      top-k (env/utils.py:132-136) -> hit points patched into hnext and the node / state images ----
+    // ---- P2: segment tests (obstacle.py:97-105) on the compacted candidate list -> alpha[agent][ray] ----
     if (do_sense) {
-#pragma unroll(NIT <= 4 ? NIT : 1)
-      for (int it = 0; it < NIT; ++it) {
-        const int i = it * 2 + hi_half;
-        const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
-        const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
-        const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
-        float amin = 1e6f, is_in = 0.0f;
-        bool bad = false;
+      // P2a: reset the per-(agent, ray) minima; candidate triples by ballot + prefix count, two agents x 32 rays per step
+      for (int q = lane; q < NA * 32 / 4; q += 64)
+        reinterpret_cast<uint4*>(L.alpha)[q] = make_uint4(MISS_BITS, MISS_BITS, MISS_BITS, MISS_BITS);
+      if (lane < ceil4(NA)) L.badm[lane] = 0u;
+      int total = 0;                                   // wave-uniform
+      const uint32_t lane_code = ((uint32_t)(hi_half * NO) << 5) | (uint32_t)r;
 #pragma unroll
-        for (int o = 0; o < NO; ++o) is_in = fmaxf(is_in, L.ino[i * NO + o]);
-DGPPO_PRAGMA(unroll DGPPO_WAVE_UNROLL_O)
+      for (int it = 0; it < NIT; ++it) {
+#pragma unroll
         for (int o = 0; o < NO; ++o) {
           const int qa = (it * 2) * NO + o, qb = (it * 2 + 1) * NO + o;
           const bool fa_ = (far[qa >> 6] >> (qa & 63)) & 1ull, fb_ = (far[qb >> 6] >> (qb & 63)) & 1ull;
-          if (fa_ && fb_) continue;                  // wave-uniform: neither agent of this iteration can reach obstacle o
-          float4 sg[4], as[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) { sg[m] = L.seg[o * 4 + m]; as[m] = L.as[(i * NO + o) * 4 + m]; }
+          if (fa_ && fb_) continue;                  // wave-uniform: neither agent of this step can reach obstacle o
+          const float4 pc = L.pc[(it * 2 + hi_half) * NO + o];
+          const float cross = cr * pc.y - sn * pc.x, dot = cr * pc.x + sn * pc.y;
+          const bool need = !(fabsf(cross) > pc.z) && !(dot < -pc.z);        // NaN keeps the triple
+          const uint64_t nm = __builtin_amdgcn_ballot_w64(need);
+          const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+          if (need) L.items[pos] = (uint16_t)(lane_code + (uint32_t)(((it * 2) * NO + o) << 5));
+          total += __builtin_popcountll(nm);
+        }
+      }
+      WSYNC();
+      PHASE("P2b_dense", 6);
+      // P2b: 64 candidates per pass, four segments each.  min over segments and obstacles through ds_min_u32 on the bit
+      // patterns (every accepted alpha is >= +0); a lane that meets det == 0 / NaN only marks its (agent, ray).
+#pragma unroll 1
+      for (int k0 = 0; k0 < total; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < total) {
+          const uint32_t item = L.items[k];
+          const int pair = (int)(item >> 5), rr = (int)(item & 31u);
+          const int i = pair / NO, o = pair - i * NO;
+          const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
+          const float crr = L.rayt[rr * 2], snr = L.rayt[rr * 2 + 1];
+          const float x2 = x1 + crr * sr, y2 = y1 + snr * sr;
+          const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
           float naf[4], adet[4];
           bool valid[4];
+          float dprod = 1.0f;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            const float det0 = dx12 * sg[m].w - dy12 * sg[m].z;
-            const float nb = ndy12 * as[m].x + dx12 * as[m].y;
+            const float4 sg = L.seg[o * 4 + m];
+            const float ax = x1 - sg.x, ay = y1 - sg.y;
+            const float na = sg.w * ax - sg.z * ay;
+            const float det0 = dx12 * sg.w - dy12 * sg.z;
+            const float nb = ndy12 * ax + dx12 * ay;
             // flip both numerators by the sign of det: (na/det, nb/det) == (na'/|det|, nb'/|det|), exactly
             const uint32_t sb = __float_as_uint(det0) & 0x80000000u;
-            naf[m] = __uint_as_float(__float_as_uint(as[m].z) ^ sb);
+            naf[m] = __uint_as_float(__float_as_uint(na) ^ sb);
             const float nbf = __uint_as_float(__float_as_uint(nb) ^ sb);
             adet[m] = __builtin_amdgcn_fmed3f(fabsf(det0), 1e-7f, 1e7f);      // clip(|det|, 1e-7, 1e7)
             const float mn = raw_min(naf[m], nbf), mx = raw_max(naf[m], nbf);
             // 0 <= q <= 1 for both quotients  <=>  0 <= min(na', nb') and max(na', nb') <= |det|   (-0 >= 0 holds, like -0/d >= 0)
             valid[m] = (mn >= 0.0f) && (mx <= adet[m]);
-            bad = bad || !(det0 != 0.0f);                                      // zero or NaN
+            dprod = dprod * det0;
           }
-          // one wave-uniform branch per obstacle: when some lane hits some segment, the four correctly rounded divisions
-          // are issued together (independent chains interleave) instead of one dependent chain per branch
+          // det == 0 or NaN on any of the four segments (a product that underflows to 0 only sends the ray to the literal
+          // path below, which is always right)
+          const bool bad = !(dprod != 0.0f);
+          float amin = 1e6f;
+          // one branch for the pass: when some lane hits some segment, the four correctly rounded divisions are issued
+          // together (independent chains interleave)
           if (__builtin_amdgcn_ballot_w64(valid[0] || valid[1] || valid[2] || valid[3]) != 0ull) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -512,28 +550,54 @@ DGPPO_PRAGMA(unroll DGPPO_WAVE_UNROLL_O)
               amin = raw_min(amin, al);
             }
           }
+          if (amin < 1e6f) atomicMin(&L.alpha[i * 32 + rr], __float_as_uint(amin));
+          if (bad) atomicOr(&L.badm[i], 1u << rr);
         }
-        PHASE("P2_slowcheck", 12 + it * 3);
-        float ar = amin;
-        if (bad) {                         // literal reference arithmetic for every segment of this lane (see lidar_step_kernel)
-          float lmin = 1e6f;
-          bool any_nan = false;
+      }
+      WSYNC();
+      PHASE("P2_slowcheck", 12);
+      // rays that met det == 0 / NaN: literal reference arithmetic over every segment (see lidar_step_kernel); practically never
+      if (__builtin_amdgcn_ballot_w64(lane < NA && L.badm[lane < NA ? lane : 0] != 0u) != 0ull) {
 #pragma unroll 1
-          for (int q = 0; q < NO * 4; ++q) {
-            const float4 sgq = L.seg[q];
-            const float4 asq = L.as[i * NO * 4 + q];
-            const float det0 = dx12 * sgq.w - dy12 * sgq.z;
-            const float nb = ndy12 * asq.x + dx12 * asq.y;
-            const float sgn = (det0 > 0.0f) ? 1.0f : ((det0 < 0.0f) ? -1.0f : det0);
-            const float dz = sgn * fminf(fmaxf(fabsf(det0), 1e-7f), 1e7f);
-            const float aq = asq.z / dz, bq = nb / dz;
-            const float v = ((aq <= 1.0f) && (aq >= 0.0f) && (bq <= 1.0f) && (bq >= 0.0f)) ? 1.0f : 0.0f;
-            const float al = v * aq + (1.0f - v) * 1e6f;
-            any_nan = any_nan || (al != al);
-            lmin = fminf(lmin, al);
+        for (int it = 0; it < NIT; ++it) {
+          const int i = it * 2 + hi_half;
+          if ((L.badm[i] >> r) & 1u) {
+            const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
+            const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
+            const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
+            float lmin = 1e6f;
+            bool any_nan = false;
+#pragma unroll 1
+            for (int q = 0; q < NO * 4; ++q) {
+              const float4 sgq = L.seg[q];
+              const float ax = x1 - sgq.x, ay = y1 - sgq.y;
+              const float na = sgq.w * ax - sgq.z * ay;
+              const float det0 = dx12 * sgq.w - dy12 * sgq.z;
+              const float nb = ndy12 * ax + dx12 * ay;
+              const float sgn = (det0 > 0.0f) ? 1.0f : ((det0 < 0.0f) ? -1.0f : det0);
+              const float dz = sgn * fminf(fmaxf(fabsf(det0), 1e-7f), 1e7f);
+              const float aq = na / dz, bq = nb / dz;
+              const float v = ((aq <= 1.0f) && (aq >= 0.0f) && (bq <= 1.0f) && (bq >= 0.0f)) ? 1.0f : 0.0f;
+              const float al = v * aq + (1.0f - v) * 1e6f;
+              any_nan = any_nan || (al != al);
+              lmin = fminf(lmin, al);
+            }
+            L.alpha[i * 32 + r] = __float_as_uint(any_nan ? __builtin_nanf("") : lmin);
           }
-          ar = any_nan ? __builtin_nanf("") : lmin;
         }
+        WSYNC();
+      }
+      // ---- P3: per step, two agents x 32 rays: stable top-k (env/utils.py:132-136) -> hit points patched into hnext and
+      //      the node / state images ----
+#pragma unroll(NIT <= 4 ? NIT : 1)
+      for (int it = 0; it < NIT; ++it) {
+        const int i = it * 2 + hi_half;
+        const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
+        const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
+        float is_in = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) is_in = fmaxf(is_in, L.ino[i * NO + o]);
+        float ar = __uint_as_float(L.alpha[i * 32 + r]);
         ar = ar * (1.0f - is_in);
         PHASE("P3_topk", 12 + it * 3 + 1);
         // sort key: float bits (alphas are >= +0), NaN -> max.  Classes: L (hit, key < 1e6), M (miss, key == 1e6), H (NaN)
