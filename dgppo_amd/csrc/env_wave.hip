@@ -47,8 +47,14 @@
 #ifndef DGPPO_WAVE_WPE
 #define DGPPO_WAVE_WPE 5
 #endif
+#ifndef DGPPO_WAVE_WPE_COMPACT      // the kernels without the GraphsTuple image (training rollout, reset's sense pass)
+#define DGPPO_WAVE_WPE_COMPACT 6
+#endif
 #ifndef DGPPO_WAVE_UNROLL_O
 #define DGPPO_WAVE_UNROLL_O 8
+#endif
+#ifndef DGPPO_WAVE_UNROLL_P3
+#define DGPPO_WAVE_UNROLL_P3 1
 #endif
 #define DGPPO_PRAGMA_(x) _Pragma(#x)
 #define DGPPO_PRAGMA(x) DGPPO_PRAGMA_(x)
@@ -89,10 +95,12 @@ struct WC {
   static_assert((NA & (NA - 1)) == 0 && NA >= 4, "wave kernel: n_agents must be a power of two >= 4 (DPP group reductions)");
   static_assert(NO >= 1 && NO * 4 <= 64, "wave kernel: 1 <= n_obs <= 16");
   static_assert((NA * SD) % 4 == 0, "agent / goal rows are staged as float4");
+  // the staged inputs agent | goal | obst | hits | act are contiguous float4 items: what is overlaid on them must not be larger
+  static_assert(ceil4(3 * NA) <= NA * SD && 4 * NA + ceil4(NA * 2) <= NO * 16, "overlays exceed the staged input they reuse");
 };
 
 // per-wave LDS slab; every member is a multiple of 16 bytes so each starts 16-byte aligned
-template <int SD, bool SPREAD, int NA, int NO>
+template <int SD, bool SPREAD, int NA, int NO, bool GRAPH>
 struct alignas(16) WaveLds {
   using C = WC<SD, SPREAD, NA, NO>;
   float4 seg[NO * 4];                 // per segment: x3, y3, ex = x4 - x3, ey = y4 - y3
@@ -100,23 +108,37 @@ struct alignas(16) WaveLds {
   float4 circ[NO];                    // cull circle: cx, cy, (R + h + 0.05)^2, h + 0.05
   uint32_t alpha[NA * 32];            // per (agent, ray): bits of min alpha over the tested segments (1e6: no hit)
   uint32_t badm[ceil4(NA)];           // per agent: rays that met det == 0 / NaN (literal re-evaluation)
-  float rayt[64];                     // ray fan: cos, sin per ray (once per wave)
-  uint16_t items[NA * NO * 32];       // candidate (agent, obstacle, ray) triples: (agent * NO + obstacle) << 5 | ray
+  // two scratch areas that are never live together share their bytes (LDS per wave decides how many waves a CU holds):
+  union {
+    uint16_t items[NA * NO * 32];     // P2: candidate (agent, obstacle, ray) triples: (agent * NO + obstacle) << 5 | ray
+    struct {                          // P3:
+      uint32_t tk[NA * 32];           //   per agent the keys of its hitting rays, compacted in ray order (0xFFFFFFFF: unused)
+      uint32_t hcnt[ceil4(NA)];       //   per agent: number of hitting rays
+      uint16_t hlist[NA * 32];        //   all hitting (agent, ray) of the env: agent << 10 | position in the agent's list << 5 | ray
+    };
+  };
   float next[ceil4(NA * SD)];         // state at t+1
   // inputs of the env, staged with ONE 16-byte load per lane: consecutive float4 items agent | goal | obst | hits | act
-  float agent[NA * SD];               // state at t
+  union {                             // state at t; dead once the cost terms of graph_t are reduced, then:
+    float agent[NA * SD];
+    float red[ceil4(3 * NA)];         //   reward terms: d2g | indicator | ||a||^2
+  };
   float goal[NA * SD];
-  float obst[NO * 16];
+  union {                             // obstacle records; dead once the segment / circle constants and the inside flags exist, then:
+    float obst[NO * 16];
+    struct {
+      float sq[4 * NA];               //   squared minima awaiting ONE square root: agent-agent | agent-hit | goal-agent | ||a||^2
+      float cost[ceil4(NA * 2)];
+    };
+  };
   float hits[NA * C::K * 2];          // hit points of graph_t until the cost terms are done, then those of graph_{t+1}
   float act[ceil4(NA * 2)];           // raw action (clipped where it is read)
-  float fa[NA * 4];                   // state2feat(next agent)
-  float fg[NA * 4];
+  float fa[SD == 4 ? 4 : NA * 4];     // state2feat(next agent) / (goal): the identity for the double integrator, whose kernels
+  float fg[SD == 4 ? 4 : NA * 4];     //   read `next` / `goal` instead (fa_ptr / fg_ptr)
   float ino[ceil4(NA * NO)];          // start-inside flags
-  float red[ceil4(3 * NA)];           // reward terms: d2g | indicator | ||a||^2
-  float cost[ceil4(NA * 2)];
-  uint32_t tk[64];                    // top-k slot lists: 32 keys per half-wave (one agent each)
-  float sq[4 * NA];                   // squared minima awaiting ONE square root: agent-agent | agent-hit | goal-agent | ||a||^2
-  float nodes[ceil4(C::N * C::ND)];   // [N, ND] image; the [N, SD] states are its leading columns (pad row: -1)
+  // [N, ND] image; the [N, SD] states are its leading columns (pad row: -1).  Only the kernels that emit the GraphsTuple
+  // carry it: without it a wave's slab is a third smaller and more waves fit a CU
+  float nodes[GRAPH ? ceil4(C::N * C::ND) : 4];
 };
 
 __device__ inline float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -162,9 +184,9 @@ __device__ inline float group_min(float x) {
 // MODE / GRAPH are compile-time: the training rollout (MODE_STEP, compact), the API step (MODE_STEP + GraphsTuple), the
 // sense-only pass of reset and the materialise-only pass each get their own straight-line code
 template <int SD, bool SPREAD, int NA, int NO, int WPB, int MODE, bool GRAPH>
-__global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(DGPPO_WAVE_WPE, 8))) lidar_wave_kernel(StepArgs a) {
+__global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(GRAPH ? DGPPO_WAVE_WPE : DGPPO_WAVE_WPE_COMPACT, 8))) lidar_wave_kernel(StepArgs a) {
   using C = WC<SD, SPREAD, NA, NO>;
-  using LT = WaveLds<SD, SPREAD, NA, NO>;
+  using LT = WaveLds<SD, SPREAD, NA, NO, GRAPH>;
   constexpr int K = C::K, ND = C::ND, N = C::N, PAD = C::PAD, NIT = C::NIT, GS = C::GS, E = C::E;
   extern __shared__ float4 smem4[];
   int lane = threadIdx.x & 63;
@@ -214,11 +236,12 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
     }
   }
   // ---- once per wave: the constant part of the node / state images (lidar_env/base.py:236-264, graph.py:214-218) ----
-  for (int i = lane; i < ceil4(N * ND) / 4; i += 64) reinterpret_cast<float4*>(L.nodes)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (do_sense) L.rayt[lane] = (lane & 1) ? a.ray_sin[lane >> 1] : a.ray_cos[lane >> 1];
+  if (has_graph)
+    for (int i = lane; i < ceil4(N * ND) / 4; i += 64) reinterpret_cast<float4*>(L.nodes)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   WSYNC();
-  for (int node = lane; node < PAD; node += 64)
-    L.nodes[node * ND + ((node < NA) ? SD + 2 : ((node < 2 * NA) ? SD + 1 : SD))] = 1.0f;
+  if (has_graph)
+    for (int node = lane; node < PAD; node += 64)
+      L.nodes[node * ND + ((node < NA) ? SD + 2 : ((node < 2 * NA) ? SD + 1 : SD))] = 1.0f;
   WSYNC();
 
   for (int b = blockIdx.x * WPB + wave; b < a.B; b += gridDim.x * WPB) {
@@ -247,6 +270,7 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
     WSYNC();
     PHASE("P1a_dyn_seg_circ", 1);
     // ---- P1a: dynamics + features (lanes < NA), goal features (lanes 32..), segment constants, cull circles ----
+    float asq = 0.0f;                              // lanes < NA: ||a_i||^2 (parked in a register: `sq` overlays the obstacle records)
     if (lane < NA) {
       const int i = lane;
       const float* x = L.agent + i * SD;
@@ -269,16 +293,19 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
           nx[2] = clampf((u0 * 10.0f) * dt + x[2], -vl, vl);
           nx[3] = clampf((u1 * 10.0f) * dt + x[3], -vl, vl);
         }
-        L.sq[3 * NA + i] = u0 * u0 + u1 * u1;     // (||a||)^2 = fl(sqrt(.))^2: the root is taken below with the distances
+        asq = u0 * u0 + u1 * u1;                  // (||a||)^2 = fl(sqrt(.))^2: the root is taken below with the distances
       } else {
 #pragma unroll
         for (int d = 0; d < SD; ++d) nx[d] = x[d];
       }
 #pragma unroll
       for (int d = 0; d < SD; ++d) L.next[i * SD + d] = nx[d];
-      state2feat<SD>(nx, L.fa + i * 4);
+      if constexpr (SD != 4) state2feat<SD>(nx, L.fa + i * 4);
     }
-    if (lane >= 32 && lane < 32 + NA) state2feat<SD>(L.goal + (lane - 32) * SD, L.fg + (lane - 32) * 4);
+    if constexpr (SD != 4)
+      if (lane >= 32 && lane < 32 + NA) state2feat<SD>(L.goal + (lane - 32) * SD, L.fg + (lane - 32) * 4);
+    const float* fa_ptr = (SD == 4) ? L.next : L.fa;
+    const float* fg_ptr = (SD == 4) ? L.goal : L.fg;
     uint32_t robust_bits = 0;                      // bit o: every (ray, edge) determinant of obstacle o is >= 1e-4 in magnitude
     if (do_sense) {
       if (lane < NO * 4) {
@@ -335,6 +362,10 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
       for (int w = 0; w < C::NFAR; ++w) far[w] = 0ull;
     }
     PHASE("P1c_cost_terms", 3);
+    if (do_dyn) {
+      WSYNC();                                       // `sq` overlays the obstacle records: every read of them is issued by now
+      if (lane < NA) L.sq[3 * NA + lane] = asq;
+    }
     if (do_dyn) {  // cost and reward terms on the PRE-step graph (lidar_env/base.py:170-171,180-207; lidar_spread.py:35-52)
       // The reference takes min_j sqrt(s_j); the correctly rounded square root is monotone, so min_j fl(sqrt(s_j)) ==
       // fl(sqrt(min_j s_j)) bit for bit: reduce the SQUARED distances and take one root per agent afterwards (the root is
@@ -447,7 +478,7 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
         const int q = q0 + lane;
         if (q < NA * NA) {
           const int i = q / NA, j = q - i * NA;
-          const float4 fi = reinterpret_cast<const float4*>(L.fa)[i], fj = reinterpret_cast<const float4*>(L.fa)[j];
+          const float4 fi = reinterpret_cast<const float4*>(fa_ptr)[i], fj = reinterpret_cast<const float4*>(fa_ptr)[j];
           const float dx = L.next[i * SD] - L.next[j * SD], dy = L.next[i * SD + 1] - L.next[j * SD + 1];
           // (sqrt(s) + (i == j ? comm_radius + 1 : 0)) < comm_radius  <=>  i != j && s < T, T = the smallest float whose
           // correctly rounded root reaches comm_radius (host-computed, sqrt_threshold()); false for NaN on both sides
@@ -462,7 +493,7 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
         const int q = q0 + lane;
         if (q < NA * GS) {
           const int i = SPREAD ? q / NA : q, g = SPREAD ? q - i * NA : q;
-          const float4 fi = reinterpret_cast<const float4*>(L.fa)[i], fg = reinterpret_cast<const float4*>(L.fg)[g];
+          const float4 fi = reinterpret_cast<const float4*>(fa_ptr)[i], fg = reinterpret_cast<const float4*>(fg_ptr)[g];
           edges[NA * NA + q] = make_float4(fi.x - fg.x, fi.y - fg.y, fi.z - fg.z, fi.w - fg.w);
           recv[NA * NA + q] = i;
           send[NA * NA + q] = NA + g;
@@ -483,22 +514,48 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
       for (int q = lane; q < NA * 32 / 4; q += 64)
         reinterpret_cast<uint4*>(L.alpha)[q] = make_uint4(MISS_BITS, MISS_BITS, MISS_BITS, MISS_BITS);
       if (lane < ceil4(NA)) L.badm[lane] = 0u;
+      // Every lane first collects, in a bit mask, which of its (step, obstacle) triples survive the two culls — straight-line
+      // arithmetic with independent LDS reads, no ballot -> scalar -> vector round trip per obstacle — then ONE wave-wide
+      // prefix sum of the per-lane counts places the survivors in the list (their order is irrelevant: results meet in a min).
       int total = 0;                                   // wave-uniform
-      const uint32_t lane_code = ((uint32_t)(hi_half * NO) << 5) | (uint32_t)r;
+      constexpr int GSTEPS = (2 * NO * NIT <= 32) ? NIT : ((32 / (2 * NO)) >= 1 ? (32 / (2 * NO)) : 1);   // steps per 32-bit mask
+      static_assert(2 * NO <= 32, "one step's triples must fit the lane mask");
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
+      for (int g0 = 0; g0 < NIT; g0 += GSTEPS) {
+        uint32_t nmask = 0u;                           // bit (it - g0) * 2 NO + o: (agent (2 it + half), obstacle o, my ray) survives
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-          const int qa = (it * 2) * NO + o, qb = (it * 2 + 1) * NO + o;
-          const bool fa_ = (far[qa >> 6] >> (qa & 63)) & 1ull, fb_ = (far[qb >> 6] >> (qb & 63)) & 1ull;
-          if (fa_ && fb_) continue;                  // wave-uniform: neither agent of this step can reach obstacle o
-          const float4 pc = L.pc[(it * 2 + hi_half) * NO + o];
-          const float cross = cr * pc.y - sn * pc.x, dot = cr * pc.x + sn * pc.y;
-          const bool need = !(fabsf(cross) > pc.z) && !(dot < -pc.z);        // NaN keeps the triple
-          const uint64_t nm = __builtin_amdgcn_ballot_w64(need);
-          const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-          if (need) L.items[pos] = (uint16_t)(lane_code + (uint32_t)(((it * 2) * NO + o) << 5));
-          total += __builtin_popcountll(nm);
+        for (int it = g0; it < g0 + GSTEPS && it < NIT; ++it) {
+#pragma unroll
+          for (int o = 0; o < NO; ++o) {
+            const int qa = (it * 2) * NO + o, qb = (it * 2 + 1) * NO + o;
+            const bool fa_ = (far[qa >> 6] >> (qa & 63)) & 1ull, fb_ = (far[qb >> 6] >> (qb & 63)) & 1ull;
+            if (fa_ && fb_) continue;                  // wave-uniform: neither agent of this step can reach obstacle o
+            const float4 pc = L.pc[(it * 2 + hi_half) * NO + o];
+            const float cross = cr * pc.y - sn * pc.x, dot = cr * pc.x + sn * pc.y;
+            const bool need = !(fabsf(cross) > pc.z) && !(dot < -pc.z);        // NaN keeps the triple
+            nmask |= need ? (1u << ((it - g0) * 2 * NO + o)) : 0u;
+          }
+        }
+        // inclusive prefix sum of the counts over the 64 lanes: 4 shifts inside each row of 16, then the row totals
+        const int cnt = __popc(nmask);
+        int inc = cnt;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);     // row_shr:1
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);     // row_shr:2
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);     // row_shr:4
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);     // row_shr:8
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+        int pos = total + inc - cnt;
+        total += __builtin_amdgcn_readlane(inc, 63);
+        // code of bit b: pair index (2 (g0 + b / 2NO) + half) NO + b % 2NO  ==  2 g0 NO + half NO + b   (b % 2NO < NO by construction)
+        const uint32_t base_code = ((uint32_t)((2 * g0 + hi_half) * NO) << 5) | (uint32_t)r;
+        while (__builtin_amdgcn_ballot_w64(nmask != 0u) != 0ull) {              // trips: the largest per-lane count (<= 2 NO GSTEPS)
+          if (nmask != 0u) {
+            const int bit = __builtin_ctz(nmask);
+            L.items[pos] = (uint16_t)(base_code + ((uint32_t)bit << 5));
+            pos += 1;
+            nmask &= nmask - 1u;
+          }
         }
       }
       WSYNC();
@@ -508,12 +565,16 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll 1
       for (int k0 = 0; k0 < total; k0 += 64) {
         const int k = k0 + lane;
+        // all 64 lanes fetch an item (lanes past the end re-read item 0): the ray's direction comes from the lane that owns
+        // the ray (lane rr holds cos / sin of ray rr) through ds_bpermute, which needs its source lanes active
+        const uint32_t item = L.items[k < total ? k : 0];
+        const int rr = (int)(item & 31u);
+        const float crr = __int_as_float(__builtin_amdgcn_ds_bpermute(rr << 2, __float_as_int(cr)));
+        const float snr = __int_as_float(__builtin_amdgcn_ds_bpermute(rr << 2, __float_as_int(sn)));
         if (k < total) {
-          const uint32_t item = L.items[k];
-          const int pair = (int)(item >> 5), rr = (int)(item & 31u);
+          const int pair = (int)(item >> 5);
           const int i = pair / NO, o = pair - i * NO;
           const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
-          const float crr = L.rayt[rr * 2], snr = L.rayt[rr * 2 + 1];
           const float x2 = x1 + crr * sr, y2 = y1 + snr * sr;
           const float dx12 = x1 - x2, dy12 = y1 - y2, ndy12 = -dy12;
           float naf[4], adet[4];
@@ -555,7 +616,7 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
         }
       }
       WSYNC();
-      PHASE("P2_slowcheck", 12);
+      PHASE("P2_slowcheck", 10);
       // rays that met det == 0 / NaN: literal reference arithmetic over every segment (see lidar_step_kernel); practically never
       if (__builtin_amdgcn_ballot_w64(lane < NA && L.badm[lane < NA ? lane : 0] != 0u) != 0ull) {
 #pragma unroll 1
@@ -587,9 +648,18 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
         }
         WSYNC();
       }
+      PHASE("P3_begin", 11);
       // ---- P3: per step, two agents x 32 rays: stable top-k (env/utils.py:132-136) -> hit points patched into hnext and
       //      the node / state images ----
-#pragma unroll(NIT <= 4 ? NIT : 1)
+      // Common case (no NaN alpha in the env): misses and inside-an-obstacle agents know their rank from a prefix count and
+      // write their point at once; the (few) hitting rays of ALL agents go to one list and are ranked 64 per pass against
+      // their agent's compacted key list, ties broken by ray order.
+      bool nan_any = false;
+      int n_hits = 0, cmaxw = 0;                        // wave-uniform: hitting rays of the env, largest per-agent count
+      for (int q = lane; q < NA * 32 / 4; q += 64)
+        reinterpret_cast<uint4*>(L.tk)[q] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      WSYNC();                                         // the keys below land after this fill (DS operations of a wave are in order)
+DGPPO_PRAGMA(unroll DGPPO_WAVE_UNROLL_P3)
       for (int it = 0; it < NIT; ++it) {
         const int i = it * 2 + hi_half;
         const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
@@ -599,75 +669,205 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
         for (int o = 0; o < NO; ++o) is_in = fmaxf(is_in, L.ino[i * NO + o]);
         float ar = __uint_as_float(L.alpha[i * 32 + r]);
         ar = ar * (1.0f - is_in);
-        PHASE("P3_topk", 12 + it * 3 + 1);
-        // sort key: float bits (alphas are >= +0), NaN -> max.  Classes: L (hit, key < 1e6), M (miss, key == 1e6), H (NaN)
-        const uint32_t kr = (ar != ar) ? 0xFFFFFFFFu : __float_as_uint(ar);
-        const uint64_t Lm = __builtin_amdgcn_ballot_w64(kr < MISS_BITS);
-        const uint64_t Mm = __builtin_amdgcn_ballot_w64(kr == MISS_BITS);
-        const uint64_t Zm = __builtin_amdgcn_ballot_w64(kr == 0u);
+        nan_any = nan_any || (ar != ar);
+        const uint32_t kr = __float_as_uint(ar);
+        // an agent that starts inside an obstacle has all 32 alphas == +0 (alpha * (1 - is_in)): ranks are the ray indices
+        const bool allz = is_in != 0.0f;
+        const bool hit = (kr < MISS_BITS) && !allz;
+        const uint64_t Lm = __builtin_amdgcn_ballot_w64(hit);
         const uint32_t lo = (uint32_t)Lm, hi = (uint32_t)(Lm >> 32);
-        const uint32_t myL = hi_half ? hi : lo;
-        const uint32_t myM = hi_half ? (uint32_t)(Mm >> 32) : (uint32_t)Mm;
-        const int cntL = __popc(myL);
-        // misses keep ray order behind all hits; NaNs behind the misses (stable ascending sort)
-        const int rank_other = (kr == MISS_BITS) ? cntL + __popc(myM & below)
-                                                 : cntL + __popc(myM) + __popc(~(myL | myM) & below);
-        // an agent that starts inside an obstacle has all 32 alphas == 0: ranks are the ray indices
-        const bool z_lo = ((uint32_t)Zm == 0xFFFFFFFFu), z_hi = ((uint32_t)(Zm >> 32) == 0xFFFFFFFFu);
-        const bool allz = hi_half ? z_hi : z_lo;
-        const bool isL = (kr < MISS_BITS) && !allz;
-        // Ranks of the hitting rays: every hitting lane puts its key into its half's slot list, compacted in ray order
-        // (slot p = number of hitting rays with a smaller index); each lane then counts the slots with a smaller key,
-        // four slots per trip of a wave-uniform loop bounded by ceil(#hits / 4) <= 8.  Unused slots hold 0xFFFFFFFF.
-        const int p = __popc(myL & below);
-        L.tk[lane] = 0xFFFFFFFFu;
-        WSYNC();
-        if (isL) L.tk[hi_half * 32 + p] = kr;
-        WSYNC();
-        const int c_lo = z_lo ? 0 : __popc(lo), c_hi = z_hi ? 0 : __popc(hi);
-        const int cmax = c_lo > c_hi ? c_lo : c_hi;
-        int rlt = 0;
-#pragma unroll 1
-        for (int cb = 0; cb < cmax; cb += 4) {
-          const uint4 ks = *reinterpret_cast<const uint4*>(&L.tk[hi_half * 32 + cb]);
-          rlt += (ks.x < kr ? 1 : 0) + (ks.y < kr ? 1 : 0) + (ks.z < kr ? 1 : 0) + (ks.w < kr ? 1 : 0);
-        }
-        // equal keys among the hits (two rays with bit-identical alpha) would need the index tie-break: they show up as
-        // two lanes claiming the same strict rank.  Detect through a second pass over the slot list (claim slot rlt with
-        // p, read it back) and only then add the tie-break term; practically never taken.
-        WSYNC();
-        if (isL) L.tk[hi_half * 32 + rlt] = (uint32_t)p;
-        WSYNC();
-        const bool lost = isL && (L.tk[hi_half * 32 + rlt] != (uint32_t)p);
-        if (__builtin_amdgcn_ballot_w64(lost) != 0ull) {
-          WSYNC();
-          L.tk[lane] = 0xFFFFFFFFu;
-          WSYNC();
-          if (isL) L.tk[hi_half * 32 + p] = kr;
-          WSYNC();
-          rlt = 0;
-#pragma unroll 1
-          for (int sl = 0; sl < cmax; ++sl) {
-            const uint32_t kj = L.tk[hi_half * 32 + sl];
-            rlt += (kj < kr || (kj == kr && sl < p)) ? 1 : 0;
-          }
-          WSYNC();
-        }
-        const int rank = allz ? r : (isL ? rlt : rank_other);
-        if (rank < K) {
+        const int n_lo = __popc(lo), n_hi = __popc(hi);
+        const int pfx = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));   // hits of the step below my lane
+        const int p = pfx - (hi_half ? n_lo : 0);                                                  // ... of my agent
+        if (lane == 0) { L.hcnt[it * 2] = (uint32_t)n_lo; L.hcnt[it * 2 + 1] = (uint32_t)n_hi; }
+        // misses keep ray order behind all hits: rank = #hits + #misses below = #hits + (r - p)
+        const int rank_direct = allz ? r : ((hi_half ? n_hi : n_lo) + r - p);
+        if (!hit && rank_direct < K) {
           const float hx = x1 + (x2 - x1) * ar, hy = y1 + (y2 - y1) * ar;
-          const int hq = i * K + rank, node = 2 * NA + hq;
+          const int hq = i * K + rank_direct, node = 2 * NA + hq;
           L.hits[hq * 2] = hx; L.hits[hq * 2 + 1] = hy;
-          L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
+          if (has_graph) { L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy; }
         }
-        PHASE("P3_end", 12 + it * 3 + 2);
+        if (hit) {
+          L.tk[i * 32 + p] = kr;
+          L.hlist[n_hits + pfx] = (uint16_t)((i << 10) | (p << 5) | r);
+        }
+        n_hits += n_lo + n_hi;
+        cmaxw = cmaxw > n_lo ? cmaxw : n_lo;
+        cmaxw = cmaxw > n_hi ? cmaxw : n_hi;
+      }
+      WSYNC();
+      if (__builtin_amdgcn_ballot_w64(nan_any) == 0ull) {
+#pragma unroll 1
+        for (int k0 = 0; k0 < n_hits; k0 += 64) {
+          const int k = k0 + lane;
+          const uint32_t rec = L.hlist[k < n_hits ? k : 0];
+          const int rr = (int)(rec & 31u);
+          const float crr = __int_as_float(__builtin_amdgcn_ds_bpermute(rr << 2, __float_as_int(cr)));
+          const float snr = __int_as_float(__builtin_amdgcn_ds_bpermute(rr << 2, __float_as_int(sn)));
+          if (k < n_hits) {
+            const int i = (int)(rec >> 10), p = (int)((rec >> 5) & 31u);
+            const uint32_t kr = L.tk[i * 32 + p];
+            int rank = 0;
+#pragma unroll 1
+            for (int cb = 0; cb < cmaxw; cb += 4) {     // wave-uniform bound; slots past an agent's count hold 0xFFFFFFFF
+              const uint4 ks = *reinterpret_cast<const uint4*>(&L.tk[i * 32 + cb]);
+              rank += ((ks.x < kr) || (ks.x == kr && cb + 0 < p)) ? 1 : 0;
+              rank += ((ks.y < kr) || (ks.y == kr && cb + 1 < p)) ? 1 : 0;
+              rank += ((ks.z < kr) || (ks.z == kr && cb + 2 < p)) ? 1 : 0;
+              rank += ((ks.w < kr) || (ks.w == kr && cb + 3 < p)) ? 1 : 0;
+            }
+            if (rank < K) {
+              const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
+              const float x2 = x1 + crr * sr, y2 = y1 + snr * sr;
+              const float ar = __uint_as_float(kr);
+              const float hx = x1 + (x2 - x1) * ar, hy = y1 + (y2 - y1) * ar;
+              const int hq = i * K + rank, node = 2 * NA + hq;
+              L.hits[hq * 2] = hx; L.hits[hq * 2 + 1] = hy;
+              if (has_graph) { L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy; }
+            }
+          }
+        }
+      } else {
+        // ---- a NaN alpha somewhere (ray parallel to an edge): three classes (hit, miss, NaN), one step
+        //      (two agents) at a time; rewrites every slot of every agent ----
+        WSYNC();
+  #pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+          const int i = it * 2 + hi_half;
+          const float x1 = L.next[i * SD], y1 = L.next[i * SD + 1];
+          const float x2 = x1 + cr * sr, y2 = y1 + sn * sr;
+          float is_in = 0.0f;
+  #pragma unroll
+          for (int o = 0; o < NO; ++o) is_in = fmaxf(is_in, L.ino[i * NO + o]);
+          float ar = __uint_as_float(L.alpha[i * 32 + r]);
+          ar = ar * (1.0f - is_in);
+          PHASE("P3_topk", 12 + it * 3 + 1);
+          int rank;
+          if (__builtin_amdgcn_ballot_w64(ar != ar) == 0ull) {
+            // ---- common case, no NaN among the 64 alphas: two classes, hit (key < 1e6) and miss (key == 1e6) ----
+            const uint32_t kr = __float_as_uint(ar);
+            const bool hit = kr < MISS_BITS;
+            const uint64_t Lm = __builtin_amdgcn_ballot_w64(hit);
+            const uint32_t lo = (uint32_t)Lm, hi = (uint32_t)(Lm >> 32);
+            const int n_lo = __popc(lo), n_hi = __popc(hi);
+            // hits of my half with a smaller ray index (prefix count over the ballot, minus the other half's total)
+            const int p = (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)) - (hi_half ? n_lo : 0);
+            // an agent that starts inside an obstacle has all 32 alphas == +0 (alpha * (1 - is_in)): ranks are the ray indices
+            const bool allz = is_in != 0.0f;
+            const bool z_lo = __builtin_amdgcn_readlane((int)allz, 0) != 0, z_hi = __builtin_amdgcn_readlane((int)allz, 32) != 0;
+            const int c_lo = z_lo ? 0 : n_lo, c_hi = z_hi ? 0 : n_hi;
+            const int cmax = c_lo > c_hi ? c_lo : c_hi;
+            // misses keep ray order behind all hits: rank = #hits + #misses below = #hits + (r - p)
+            rank = allz ? r : ((hi_half ? n_hi : n_lo) + r - p);
+            if (cmax > 0) {                            // wave-uniform: some agent of this step has hits to order
+              const bool isL = hit && !allz;
+              // every hitting lane puts its key into its half's slot list, compacted in ray order; each lane then counts the
+              // slots with a smaller key, four slots per trip of a wave-uniform loop.  Unused slots hold 0xFFFFFFFF.
+              L.tk[lane] = 0xFFFFFFFFu;
+              WSYNC();
+              if (isL) L.tk[hi_half * 32 + p] = kr;
+              WSYNC();
+              int rlt = 0;
+  #pragma unroll 1
+              for (int cb = 0; cb < cmax; cb += 4) {
+                const uint4 ks = *reinterpret_cast<const uint4*>(&L.tk[hi_half * 32 + cb]);
+                rlt += (ks.x < kr ? 1 : 0) + (ks.y < kr ? 1 : 0) + (ks.z < kr ? 1 : 0) + (ks.w < kr ? 1 : 0);
+              }
+              // bit-identical alphas among the hits need the index tie-break: they show up as two lanes claiming the same
+              // strict rank (claim slot rlt with p, read it back); practically never taken
+              WSYNC();
+              if (isL) L.tk[hi_half * 32 + rlt] = (uint32_t)p;
+              WSYNC();
+              const bool lost = isL && (L.tk[hi_half * 32 + rlt] != (uint32_t)p);
+              if (__builtin_amdgcn_ballot_w64(lost) != 0ull) {
+                WSYNC();
+                L.tk[lane] = 0xFFFFFFFFu;
+                WSYNC();
+                if (isL) L.tk[hi_half * 32 + p] = kr;
+                WSYNC();
+                rlt = 0;
+  #pragma unroll 1
+                for (int sl = 0; sl < cmax; ++sl) {
+                  const uint32_t kj = L.tk[hi_half * 32 + sl];
+                  rlt += (kj < kr || (kj == kr && sl < p)) ? 1 : 0;
+                }
+                WSYNC();
+              }
+              if (isL) rank = rlt;
+            }
+          } else {
+            // ---- a NaN alpha somewhere (ray parallel to an edge): three classes, general code ----
+            // sort key: float bits (alphas are >= +0), NaN -> max.  Classes: L (hit, key < 1e6), M (miss, key == 1e6), H (NaN)
+            const uint32_t kr = (ar != ar) ? 0xFFFFFFFFu : __float_as_uint(ar);
+            const uint64_t Lm = __builtin_amdgcn_ballot_w64(kr < MISS_BITS);
+            const uint64_t Mm = __builtin_amdgcn_ballot_w64(kr == MISS_BITS);
+            const uint64_t Zm = __builtin_amdgcn_ballot_w64(kr == 0u);
+            const uint32_t lo = (uint32_t)Lm, hi = (uint32_t)(Lm >> 32);
+            const uint32_t myL = hi_half ? hi : lo;
+            const uint32_t myM = hi_half ? (uint32_t)(Mm >> 32) : (uint32_t)Mm;
+            const int cntL = __popc(myL);
+            // misses keep ray order behind all hits; NaNs behind the misses (stable ascending sort)
+            const int rank_other = (kr == MISS_BITS) ? cntL + __popc(myM & below)
+                                                     : cntL + __popc(myM) + __popc(~(myL | myM) & below);
+            // an agent that starts inside an obstacle has all 32 alphas == 0: ranks are the ray indices
+            const bool z_lo = ((uint32_t)Zm == 0xFFFFFFFFu), z_hi = ((uint32_t)(Zm >> 32) == 0xFFFFFFFFu);
+            const bool allz = hi_half ? z_hi : z_lo;
+            const bool isL = (kr < MISS_BITS) && !allz;
+            // Ranks of the hitting rays: every hitting lane puts its key into its half's slot list, compacted in ray order
+            // (slot p = number of hitting rays with a smaller index); each lane then counts the slots with a smaller key,
+            // four slots per trip of a wave-uniform loop bounded by ceil(#hits / 4) <= 8.  Unused slots hold 0xFFFFFFFF.
+            const int p = __popc(myL & below);
+            L.tk[lane] = 0xFFFFFFFFu;
+            WSYNC();
+            if (isL) L.tk[hi_half * 32 + p] = kr;
+            WSYNC();
+            const int c_lo = z_lo ? 0 : __popc(lo), c_hi = z_hi ? 0 : __popc(hi);
+            const int cmax = c_lo > c_hi ? c_lo : c_hi;
+            int rlt = 0;
+    #pragma unroll 1
+            for (int cb = 0; cb < cmax; cb += 4) {
+              const uint4 ks = *reinterpret_cast<const uint4*>(&L.tk[hi_half * 32 + cb]);
+              rlt += (ks.x < kr ? 1 : 0) + (ks.y < kr ? 1 : 0) + (ks.z < kr ? 1 : 0) + (ks.w < kr ? 1 : 0);
+            }
+            // equal keys among the hits (two rays with bit-identical alpha) would need the index tie-break: they show up as
+            // two lanes claiming the same strict rank.  Detect through a second pass over the slot list (claim slot rlt with
+            // p, read it back) and only then add the tie-break term; practically never taken.
+            WSYNC();
+            if (isL) L.tk[hi_half * 32 + rlt] = (uint32_t)p;
+            WSYNC();
+            const bool lost = isL && (L.tk[hi_half * 32 + rlt] != (uint32_t)p);
+            if (__builtin_amdgcn_ballot_w64(lost) != 0ull) {
+              WSYNC();
+              L.tk[lane] = 0xFFFFFFFFu;
+              WSYNC();
+              if (isL) L.tk[hi_half * 32 + p] = kr;
+              WSYNC();
+              rlt = 0;
+    #pragma unroll 1
+              for (int sl = 0; sl < cmax; ++sl) {
+                const uint32_t kj = L.tk[hi_half * 32 + sl];
+                rlt += (kj < kr || (kj == kr && sl < p)) ? 1 : 0;
+              }
+              WSYNC();
+            }
+            rank = allz ? r : (isL ? rlt : rank_other);
+          }
+          if (rank < K) {
+            const float hx = x1 + (x2 - x1) * ar, hy = y1 + (y2 - y1) * ar;
+            const int hq = i * K + rank, node = 2 * NA + hq;
+            L.hits[hq * 2] = hx; L.hits[hq * 2 + 1] = hy;
+            if (has_graph) { L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy; }
+          }
+          PHASE("P3_end", 12 + it * 3 + 2);
+        }
       }
     } else {
       // materialise-only: the hit points are given
       for (int q = lane; q < NA * K; q += 64) {
         const float hx = L.hits[q * 2], hy = L.hits[q * 2 + 1];
         const int node = 2 * NA + q;
-        L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy;
+        if (has_graph) { L.nodes[node * ND] = hx; L.nodes[node * ND + 1] = hy; }
       }
     }
     WSYNC();
@@ -736,12 +936,11 @@ __global__ void __launch_bounds__(WPB * 64) __attribute__((amdgpu_waves_per_eu(D
 
 template <int SD, bool SPREAD, int NA, int NO>
 bool launch_inst(const StepArgs& a, hipStream_t s) {
-  using LT = WaveLds<SD, SPREAD, NA, NO>;
-  constexpr size_t per_wave = sizeof(LT);
+  constexpr size_t per_wave = sizeof(WaveLds<SD, SPREAD, NA, NO, true>);        // the larger of the two layouts
   // waves per workgroup: as many independent waves as keep several workgroups resident in the 160 KiB of a CU
   constexpr int WPB = (per_wave * 4 <= 40 * 1024) ? 4 : ((per_wave * 2 <= 52 * 1024) ? 2 : 1);
   static_assert(per_wave * WPB <= 64 * 1024, "LDS slab too large");
-  constexpr size_t smem = per_wave * WPB;
+  constexpr size_t smem_g = per_wave * WPB, smem_c = sizeof(WaveLds<SD, SPREAD, NA, NO, false>) * WPB;
   // persistent grid = what is actually resident (registers, LDS and wave slots together): ask the runtime once per
   // instantiation; a larger grid would leave a second, partial round of workgroups behind the first
   static int per_cu_cached[3][2] = {{0, 0}, {0, 0}, {0, 0}};
@@ -749,7 +948,7 @@ bool launch_inst(const StepArgs& a, hipStream_t s) {
   if (per_cu == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
-#define OCC(M_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lidar_wave_kernel<SD, SPREAD, NA, NO, WPB, M_, G_>, WPB * 64, smem)
+#define OCC(M_, G_) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, lidar_wave_kernel<SD, SPREAD, NA, NO, WPB, M_, G_>, WPB * 64, (G_) ? smem_g : smem_c)
     if (a.mode == MODE_STEP) { if (a.has_graph) OCC(MODE_STEP, true); else OCC(MODE_STEP, false); }
     else if (a.mode == MODE_SENSE) { if (a.has_graph) OCC(MODE_SENSE, true); else OCC(MODE_SENSE, false); }
     else OCC(MODE_GRAPH, true);
@@ -776,8 +975,10 @@ bool launch_inst(const StepArgs& a, hipStream_t s) {
     const int want = (a.B + WPB * atoi(wpe) - 1) / (WPB * atoi(wpe));
     if (want >= 1 && want < blocks) blocks = want;
   }
+  const char* gpe = getenv("DGPPO_WAVE_GRID_ENVS");   // tuning knob: exactly this many envs per wave, grid NOT capped at the resident set
+  if (gpe && atoi(gpe) >= 1) blocks = (a.B + WPB * atoi(gpe) - 1) / (WPB * atoi(gpe));
   const dim3 g(blocks), t(WPB * 64);
-#define LAUNCH(M_, G_) hipLaunchKernelGGL((lidar_wave_kernel<SD, SPREAD, NA, NO, WPB, M_, G_>), g, t, smem, s, a)
+#define LAUNCH(M_, G_) hipLaunchKernelGGL((lidar_wave_kernel<SD, SPREAD, NA, NO, WPB, M_, G_>), g, t, (G_) ? smem_g : smem_c, s, a)
   if (a.mode == MODE_STEP) { if (a.has_graph) LAUNCH(MODE_STEP, true); else LAUNCH(MODE_STEP, false); }
   else if (a.mode == MODE_SENSE) { if (a.has_graph) LAUNCH(MODE_SENSE, true); else LAUNCH(MODE_SENSE, false); }
   else LAUNCH(MODE_GRAPH, true);

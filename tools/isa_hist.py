@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Instruction-class histogram of one kernel from hipcc's assembly, per phase, priced with the cycle table of
-MI355X_MICROARCH.md ("Per-instruction cycle constants") — VERDICT r2 item 3: where do the issue slots of
+"""Instruction-class histogram of one kernel from hipcc's assembly, per phase, priced with issue rates MEASURED on MI355X
+(tools/micro/valu_rate.hip -> profiles/r03_valu_issue_rates.json; MI355X_MICROARCH.md's table gives 2 cycles for v_fma_f32 only) — VERDICT r2 item 3: where do the issue slots of
 lidar_wave_kernel<4,true,8,3,4,0,true> go?
 
     python tools/isa_hist.py [--kernel SUBSTR] [--out profiles/r03_env_wave_isa_hist.json]
@@ -26,11 +26,25 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-pass-failed", "-ffp-contract=off",
          "-S", "--cuda-device-only"]
 
-# issue cost in cycles of a wave64 instruction on its SIMD with several waves resident (MI355X_MICROARCH.md: v_fma_f32 2 cyc
-# SIMD-32 throughput; transcendentals 8 = 4x the one-wave 4-cycle base -> 2x here is not documented, the table's ratio is
-# kept: 2 -> 4).  64-bit integer / f64 ops and v_div_fixup/fmas/scale are full-rate encodings on CDNA (VOP3, 2 passes).
-PRICE = {"valu_full": 2, "valu_trans": 4, "valu_dpp": 2, "valu_xlane": 2, "valu_cmp": 2, "valu_div": 2, "lds": 2, "vmem": 2,
-         "salu": 1, "smem": 1, "branch": 1, "waitcnt": 0, "nop": 1}
+# Cycles a wave64 instruction occupies its pipe, per SIMD, with the pipe saturated (>= 4 waves per SIMD) — MEASURED on MI355X
+# with tools/micro/valu_rate.hip (profiles/r03_valu_issue_rates.json), not taken from the guide's table:
+#   * "full": v_add / v_sub / v_mul / v_fma / v_fmac _f32, v_mov_b32, v_and / v_xor / v_or _b32, v_add_u32 ... 2.3 cycles
+#   * "half": v_min / v_max / v_med3 _f32, every v_cmp*, v_cndmask, shifts, v_bfe, v_mad_u32_u24, v_div_scale / fmas / fixup,
+#     every DPP form, v_readlane, v_pk_mul_f32 (two multiplies) ... 4.2 cycles — HALF rate
+#   * "trans": v_rcp / v_sqrt ... 8.2 cycles
+#   * SALU: 4.2 cycles per SIMD (one scalar pipe per CU, shared by its four SIMDs); overlaps with the VALU of other waves
+#   * ds_read_b128: ~23 cycles per SIMD (LDS return path: 1 KiB per wave-instruction), same for a broadcast address
+#   * a single wave issues at most one instruction per ~4.6 cycles, whatever the class
+# (mnemonics that were not measured are put with their nearest measured relative and marked in MEASURED below)
+PRICE = {"valu_full": 2.3, "valu_half": 4.2, "valu_trans": 8.2, "lds": 16.0, "vmem": 4.0, "salu": 4.2, "smem": 4.2, "branch": 4.2,
+         "waitcnt": 0.0, "nop": 1.2}
+FULL = ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mov_b32", "v_and_b32", "v_or_b32",
+        "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_not_b32", "v_add_co_u32", "v_addc_co_u32")
+MEASURED = {"full": ["v_fma_f32", "v_mul_f32", "v_add_f32", "v_mov_b32", "v_and_b32", "v_xor_b32", "v_add_u32"],
+            "half": ["v_min_f32", "v_med3_f32", "v_bfe_u32", "v_lshlrev_b32", "v_mad_u32_u24", "v_cndmask_b32", "v_cmp_lt_f32",
+                     "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32", "v_mov_b32_dpp", "v_min_f32_dpp", "v_readlane_b32",
+                     "v_pk_mul_f32"],
+            "trans": ["v_rcp_f32", "v_sqrt_f32"], "salu": ["s_and_b64"], "lds": ["ds_read_b128"], "nop": ["s_nop 0"]}
 
 TRANS = ("v_rcp", "v_rsq", "v_sqrt", "v_exp", "v_log", "v_sin", "v_cos")
 
@@ -50,18 +64,15 @@ def classify(mn: str, ops: str) -> str:
         return "lds"
     if mn.startswith(("global_", "buffer_", "flat_", "scratch_")):
         return "vmem"
-    if mn.startswith(("v_readlane", "v_readfirstlane", "v_writelane", "v_permlane", "v_bpermute")):
-        return "valu_xlane"
-    if "dpp" in ops or "row_" in ops or "quad_perm" in ops or mn.endswith("_dpp"):
-        return "valu_dpp"
     if mn.startswith(TRANS):
         return "valu_trans"
-    if mn.startswith(("v_div_scale", "v_div_fmas", "v_div_fixup")):
-        return "valu_div"
-    if mn.startswith("v_cmp") or mn.startswith("v_cndmask"):
-        return "valu_cmp"
-    if mn.startswith("v_"):
+    if "dpp" in ops or "row_" in ops or "quad_perm" in ops or mn.endswith("_dpp"):
+        return "valu_half"
+    base = mn[:-4] if mn.endswith(("_e32", "_e64")) else mn
+    if base in FULL:
         return "valu_full"
+    if mn.startswith("v_"):
+        return "valu_half"
     return "other"
 
 
@@ -111,7 +122,13 @@ def compile_asm(src: str, extra):
 
 
 def priced(counter):
-    return sum(PRICE.get(k, 2) * v for k, v in counter.items())
+    """cycles of the busiest pipe's work if nothing overlapped within a class; VALU, SALU and LDS are separate pipes, so the
+    VALU sum is the number to hold against the measured cycles per env and SIMD"""
+    return round(sum(PRICE.get(k, 2.3) * v for k, v in counter.items()), 1)
+
+
+def priced_valu(counter):
+    return round(sum(PRICE[k] * v for k, v in counter.items() if k.startswith("valu")), 1)
 
 
 def main():
@@ -138,8 +155,10 @@ def main():
         "kernel": a.kernel, "flags": " ".join(FLAGS[:-2]),
         "static_counts": dict(total), "static_valu": valu,
         "priced_cycles_static": priced(total),
-        "price_table_cycles_per_wave64_instruction": PRICE,
-        "per_phase": {k: {"counts": dict(v), "valu": sum(x for kk, x in v.items() if kk.startswith("valu")), "priced_cycles": priced(v)}
+        "price_table_cycles_per_wave64_instruction_per_simd": PRICE, "price_table_source": "profiles/r03_valu_issue_rates.json (measured)",
+        "measured_mnemonics": MEASURED, "priced_valu_cycles_static": priced_valu(total),
+        "per_phase": {k: {"counts": dict(v), "valu": sum(x for kk, x in v.items() if kk.startswith("valu")), "priced_valu_cycles": priced_valu(v),
+                          "priced_cycles": priced(v)}
                       for k, v in merged.items()},
         "top_mnemonics": mn_counts.most_common(45),
     }
@@ -153,8 +172,8 @@ def main():
     print(f"kernel {a.kernel}: static {sum(total.values())} instructions, {valu} VALU; priced {priced(total)} cycles")
     print(f"{'phase':24s} " + " ".join(f"{k[:9]:>9s}" for k in PRICE) + "   priced")
     for name, c in merged.items():
-        print(f"{name:24s} " + " ".join(f"{c.get(k, 0):9d}" for k in PRICE) + f"   {priced(c):6d}")
-    print(f"{'TOTAL (production build)':24s} " + " ".join(f"{total.get(k, 0):9d}" for k in PRICE) + f"   {priced(total):6d}")
+        print(f"{name:24s} " + " ".join(f"{c.get(k, 0):9d}" for k in PRICE) + f"   {priced(c):8.0f}")
+    print(f"{'TOTAL (production build)':24s} " + " ".join(f"{total.get(k, 0):9d}" for k in PRICE) + f"   {priced(total):8.0f}   (VALU pipe alone: {priced_valu(total):.0f})")
     print("top mnemonics:", ", ".join(f"{m}:{n}" for m, n in mn_counts.most_common(30)))
 
 

@@ -8,8 +8,9 @@ from dgppo_amd import _native as N, ops_env as OE
 dev = torch.device("cuda:0")
 cfg = N.make_env_cfg(0, 8, 3)
 names = {0: "P0 stage", 1: "P1a dyn/seg/circ", 2: "P1b far/as", 3: "P1c cost terms", 4: "P1d reward + early outputs",
-         5: "P2 rays (all 4 it)", 7: "P4 late compact", 8: "P5 late graph", 9: "env end"}
-order = [0, 1, 2, 3, 4, 5, 7, 8, 9]
+         5: "P2a candidate list", 6: "P2b dense segment tests", 10: "P2c bad-ray check", 11: "P3 top-k (all 4 steps)",
+         7: "P4 late compact", 8: "P5 late graph", 9: "env end"}
+order = [0, 1, 2, 3, 4, 5, 6, 10, 11, 7, 8, 9]
 for B in (1, 4096, 16384):
     seeds = torch.arange(1, B + 1, dtype=torch.int64, device=dev) * 7919
     agent = torch.empty(B, 8, 4, device=dev); goal = torch.empty(B, 8, 4, device=dev); obst = torch.empty(B, 3, 16, device=dev)
@@ -32,8 +33,8 @@ for B in (1, 4096, 16384):
         print(f"   {names[a_]:28s} {int(st[b_] - st[a_]):7d}")
     for it in range(4):
         b0 = 12 + it * 3
-        prev = st[5] if it == 0 else st[12 + (it - 1) * 3 + 2]
-        print(f"   it {it}: segment tests {int(st[b0] - prev):6d}  slow-check+key {int(st[b0 + 1] - st[b0]):6d}  top-k+hit write {int(st[b0 + 2] - st[b0 + 1]):6d}")
+        prev = st[11] if it == 0 else st[12 + (it - 1) * 3 + 2]
+        print(f"   step {it}: alpha read + key {int(st[b0 + 1] - prev):6d}  top-k + hit write {int(st[b0 + 2] - st[b0 + 1]):6d}")
     if B >= 4096:
         sp = (C.c_ulonglong * (3 * 8192))()
         N.lib().dgppo_debug_wave_spans(sp)
