@@ -20,7 +20,7 @@ import shutil
 import statistics
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = f"gpurun_out/profiles_{TAG}"
 DST = "profiles"
 KERNEL = "lidar_wave_kernel"
@@ -151,8 +151,76 @@ def insts():
     return res
 
 
+def _short(name):
+    """kernel name without the argument list"""
+    return name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+
+
+def nn_counters():
+    """Per update-phase kernel (tools/prof_update_only.py, MS=0 REPS=1: value pre-passes + 32 minibatches, single stream):
+    calls and average duration from the kernel trace, HBM bytes per call from the FETCH_SIZE / WRITE_SIZE passes (KB units;
+    FETCH_SIZE doubled: gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md "HBM"), matrix-core busy cycles and
+    MFMA instruction counts, LDS bank conflicts — every counter from its own `--pmc`-only pass."""
+    kt = find("update_kt", "kernel_trace.csv")
+    if not kt:
+        return None
+    dur = {}
+    for r in csv.DictReader(open(kt)):
+        dur.setdefault(_short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    ctr = {}
+    for sub in ("nn_fetch", "nn_write", "nn_mfma", "nn_lds"):
+        path = find(sub, "counter_collection.csv")
+        if not path:
+            continue
+        for r in csv.DictReader(open(path)):
+            ctr.setdefault(_short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    total_us = sum(sum(v) for v in dur.values())
+    out = []
+    for name, d in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        if sum(d) < 0.004 * total_us:
+            continue
+        c = {k: sum(v) / len(v) for k, v in ctr.get(name, {}).items()}          # per call
+        row = {"kernel": name, "calls": len(d), "avg_us": statistics.mean(d), "total_ms": sum(d) / 1e3,
+               "share_of_kernel_time": sum(d) / total_us}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            rd, wr = 2.0 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
+            row.update({"hbm_read_MB_per_call_fetch_x2": rd / 1e6, "hbm_write_MB_per_call": wr / 1e6,
+                        "hbm_GBps_at_avg_duration": (rd + wr) / statistics.mean(d) / 1e3,
+                        "hbm_frac_of_8TBps": (rd + wr) / statistics.mean(d) / 1e3 / 8000.0})
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            # busy cycles summed over the SIMDs the counter samples; GRBM_GUI_ACTIVE is summed over the 8 XCDs (guide: DVFS)
+            act = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            row.update({"mfma_busy_cycles_per_call": c["SQ_VALU_MFMA_BUSY_CYCLES"], "mfma_f32_insts_per_call": c.get("SQ_INSTS_VALU_MFMA_F32"),
+                        "mfma_mops_f32_per_call": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32"), "sq_busy_cycles_per_call": c.get("SQ_BUSY_CYCLES"),
+                        "gpu_active_cycles_per_call": act or None,
+                        "mfma_busy_frac": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * act)) if act else None,
+                        "valu_insts_per_call": c.get("SQ_INSTS_VALU"), "waves_per_call": c.get("SQ_WAVES")})
+        if "SQ_LDS_BANK_CONFLICT" in c:
+            row.update({"lds_bank_conflict_cycles_per_call": c["SQ_LDS_BANK_CONFLICT"], "lds_idx_active_per_call": c.get("SQ_LDS_IDX_ACTIVE"),
+                        "lds_conflict_frac": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
+                        "wait_any_frac": (c["SQ_WAIT_ANY"] / (c["SQ_WAIT_ANY"] + c["SQ_WAIT_INST_ANY"] + c["SQ_ACTIVE_INST_ANY"]))
+                        if all(k in c for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")) else None,
+                        "wait_inst_frac": (c["SQ_WAIT_INST_ANY"] / (c["SQ_WAIT_ANY"] + c["SQ_WAIT_INST_ANY"] + c["SQ_ACTIVE_INST_ANY"]))
+                        if all(k in c for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")) else None})
+        out.append(row)
+    mfma_busy = sum(r.get("mfma_busy_cycles_per_call", 0.0) * r["calls"] for r in out)
+    active = sum((r.get("gpu_active_cycles_per_call") or 0.0) * r["calls"] for r in out)
+    res = {"command": "MS=0 REPS=1 rocprofv3 {--kernel-trace --stats | --pmc <one group>} -- python3 tools/prof_update_only.py",
+           "workload": "LidarSpread n=8 obs=3, 4096 envs x T=128: value pre-passes + 2 GAE + 32 minibatches (Vl, Vh, policy), one stream",
+           "total_kernel_ms": total_us / 1e3,
+           "update_mfma_busy_frac": (mfma_busy / (1024.0 * active)) if active else None,
+           "units": "FETCH_SIZE / WRITE_SIZE in KB; *_cycles summed over the SIMDs sampled; mfma_busy_frac = busy cycles / (1024 SIMDs x "
+                    "GRBM_GUI_ACTIVE / 8); kernels below 0.4 % of the kernel time are omitted",
+           "kernels": out}
+    json.dump(res, open(f"{DST}/{TAG}_nn_counters.json", "w"), indent=1)
+    return res
+
+
 def main():
     os.makedirs(DST, exist_ok=True)
+    nn = nn_counters()
+    if nn:
+        print("nn counters:", len(nn["kernels"]), "kernels; update mfma busy frac", nn["update_mfma_busy_frac"])
     print(json.dumps(trace_summary(), indent=1))
     print(json.dumps(traffic(), indent=1))
     print(json.dumps(insts(), indent=1))
@@ -167,6 +235,10 @@ def main():
             json.dump(json.loads(lines[-1]), open(f"{DST}/{TAG}_bench_line.json", "w"), indent=1)
     if os.path.exists(f"{SRC}/stamps.log"):
         shutil.copy(f"{SRC}/stamps.log", f"{DST}/{TAG}_env_wave_stamps.txt")
+    if os.path.exists(f"{SRC}/valu_rate.log"):
+        txt = open(f"{SRC}/valu_rate.log").read()
+        if txt.strip().startswith("{"):
+            open(f"{DST}/{TAG}_valu_issue_rates.json", "w").write(txt)
 
 
 if __name__ == "__main__":
