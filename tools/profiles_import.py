@@ -127,26 +127,42 @@ def traffic():
 
 
 def insts():
-    rows = pmc_rows("env_insts")
-    if not rows:
-        return None
-    g = max(int(r["Grid_Size"]) for r in rows)
+    """SQ instruction / wait counters of the raycast+graph kernel per launch size (SIZES=4096,16384: the two largest grids
+    that were launched >= 50 times, in that order), for the materialised and the compact variant"""
     res = {}
-    for variant, want in (("api", True), ("compact", False)):
-        sel = [r for r in rows if int(r["Grid_Size"]) == g and is_graph(r["Kernel_Name"]) == want and mode_of(r["Kernel_Name"]) == "0"]
-        c = {}
-        for r in sel:
-            c.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-        c = {k: statistics.median(v) for k, v in c.items()}
-        if not c:
+    for sub in ("env_insts", "env_insts2"):
+        rows = pmc_rows(sub)
+        if not rows:
             continue
-        waves = c.get("SQ_WAVES", 0) or 1
-        res[variant] = {"counters_per_launch": c, "waves_per_launch": waves, "envs_per_launch": 4096,
-                        "per_wave": {k: v / waves for k, v in c.items() if k.startswith("SQ_INSTS")},
-                        "per_env": {k: v / 4096 for k, v in c.items() if k.startswith("SQ_INSTS")}}
-    res["note"] = ("rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
-                   "SQ_ACTIVE_INST_VALU over SIZES=4096 tools/bench_env.py; persistent waves walk several envs each, so the "
-                   "per-env figure (not the per-wave one) is what compares with round 1's 2 waves x 1 661 VALU = 3 322 per env")
+        for variant, want in (("api", True), ("compact", False)):
+            sel = [r for r in rows if is_graph(r["Kernel_Name"]) == want and mode_of(r["Kernel_Name"]) == "0"]
+            by_grid = {}
+            for r in sel:
+                by_grid.setdefault(int(r["Grid_Size"]), []).append(r)
+            n_ctr = len({r["Counter_Name"] for r in sel}) or 1
+            grids = sorted(g for g, v in by_grid.items() if len(v) >= 50 * n_ctr)[-2:]
+            for g, envs in zip(grids, (4096, 16384)[-len(grids):]):
+                c = {}
+                for r in by_grid[g]:
+                    c.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                c = {k: statistics.median(v) for k, v in c.items()}
+                d = res.setdefault(variant, {}).setdefault(str(envs), {"envs_per_launch": envs, "grid_threads": g, "counters_per_launch": {}})
+                d["counters_per_launch"].update(c)
+    for variant in res:
+        for d in res[variant].values():
+            c, envs = d["counters_per_launch"], d["envs_per_launch"]
+            d["waves_per_launch"] = c.get("SQ_WAVES")
+            d["per_env"] = {k: v / envs for k, v in c.items() if k.startswith("SQ_INSTS")}
+            if "SQ_WAVE_CYCLES" in c:        # quad-cycles -> cycles of wave lifetime per env, and where they go
+                d["wave_cycles_per_env"] = 4.0 * c["SQ_WAVE_CYCLES"] / envs
+                d["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+                d["wait_inst_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+                d["active_valu_frac"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]
+    if not res:
+        return None
+    res["note"] = ("two rocprofv3 --pmc passes (8 SQ counters each) over SIZES=4096,16384 tools/bench_env.py; SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                   "SQ_ACTIVE_* count quad-cycles; persistent waves walk several envs each at 16 384 envs, so the per-env figures are "
+                   "the comparable ones (round 2: 1 698 VALU + 525 SALU + 170 LDS per env; round 1: 3 322 + 1 782 + 300)")
     json.dump(res, open(f"{DST}/{TAG}_env_step_insts.json", "w"), indent=1)
     return res
 
