@@ -312,16 +312,26 @@ def main():
                  "note": "network multiply-add work of one rank's iteration / its wall time (wall time includes rollouts, GAE and all "
                          "non-MFMA kernels; < 2 % of the counted flops run on the VALU: the first GNN layer's slot-sparse attention "
                          "and the K <= 16 dense kernels)"},
+        "peaks_note": "fp32 VALU issue rates measured on this part: profiles/r03_valu_issue_rates.json",
         "peaks": {"hbm_GBps": HBM_PEAK_GBS, "fp32_TFLOPs": FP32_PEAK_TFLOPS, "source": "MI355X_MICROARCH.md (spec values)",
                   "device": torch.cuda.get_device_name(device)},
         "last_info": {k: info[k] for k in ("policy/loss", "Vl/loss", "Vh/loss_Vh", "eval/safe_data")},
     }
+    nnc = os.path.join(ROOT, "profiles", "r03_nn_counters.json")
+    if os.path.exists(nnc):
+        # matrix-core busy fraction of the update phase from the committed counter passes (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
+        # GRBM_GUI_ACTIVE ..., tools/collect_profiles.sh): measured offline, like roofline.traffic
+        try:
+            out["mfma"]["mfma_busy"] = json.load(open(nnc))["update_mfma_busy_frac"]
+            out["mfma"]["mfma_busy_source"] = "profiles/r03_nn_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) over the update phase (offline pass)"
+        except Exception:
+            pass
     if world > 1:
         out["multi_gpu"] = {"rccl_version": D.rccl_version(), "devices_visible": n_dev, "backend": backend,
                             "allreduce_selfcheck": "passed"}
     if rl is not None:
         traffic, tsrc = None, None
-        for name in ("r02_env_step_traffic.json", "r01_env_step_traffic.json"):
+        for name in ("r03_env_step_traffic.json", "r02_env_step_traffic.json", "r01_env_step_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and B == 4096 and args.env == "LidarSpread" and args.num_agents == 8 and args.obs == 3:
                 # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE), see profiles/README.md
