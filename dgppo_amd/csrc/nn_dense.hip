@@ -75,7 +75,11 @@ __global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
   extern __shared__ float xs_all[];
   constexpr int RG = 4 / CG, RB = 16 * RTW * RG;
   constexpr int KS = KQ * 4;                                   // k-steps of 4 (one MFMA each)
-  constexpr int Kl = KQ * 16 + 1;                              // odd LDS row stride: conflict-free A-fragment reads
+  // LDS row stride = 2 (mod 32) floats: an A-fragment read touches banks (2 li + lq) mod 32, all distinct inside each half of
+  // the wave (lq in {0,1} / {2,3}); the odd stride used before put (li, lq = 1) and (li + 1, lq = 0) on the same bank whenever KQ
+  // is even (K = 32, 64, 192): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.5 (profiles/r03_nn_counters.json).  It also makes
+  // every float4 slot 8-byte aligned: two ds_write_b64 per slot instead of four ds_write_b32.
+  constexpr int Kl = KQ * 16 + 2;
   constexpr int SLOTS = RB * KS;                               // float4 slots per tile
   constexpr int PF = (SLOTS + 255) / 256;                      // prefetch registers (float4) per lane
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,9 +129,10 @@ __global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
       int idx = u * 256 + tid;
       idx = idx < SLOTS ? idx : SLOTS - 1;
       const int r = idx / KS, q = idx - r * KS;
-      float* d = xs + r * Kl + 4 * q;
+      float2* d = reinterpret_cast<float2*>(xs + r * Kl + 4 * q);
       const bool pad = q >= K4;                                // touching pf only here keeps the loads in flight
-      d[0] = pad ? 0.0f : pf[u].x; d[1] = pad ? 0.0f : pf[u].y; d[2] = pad ? 0.0f : pf[u].z; d[3] = pad ? 0.0f : pf[u].w;
+      d[0] = pad ? make_float2(0.0f, 0.0f) : make_float2(pf[u].x, pf[u].y);
+      d[1] = pad ? make_float2(0.0f, 0.0f) : make_float2(pf[u].z, pf[u].w);
     }
   };
   auto stage_scalar = [&](int tile, int b) {   // unaligned / K % 4 != 0 fallback (no prefetch)
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
 template <int NTW, int RTW, int CG, int KQ, bool ACC>
 static void launch_dense_acc(const DenseArgs& a, hipStream_t s) {
   constexpr int RB = 16 * RTW * (4 / CG);
-  constexpr size_t smem = 2 * (size_t)RB * (KQ * 16 + 1) * sizeof(float);
+  constexpr size_t smem = 2 * (size_t)RB * (KQ * 16 + 2) * sizeof(float);
   static_assert(smem <= 160 * 1024, "dense tile exceeds the 160 KB LDS of a gfx950 CU");
   // persistent grid = what is actually resident (registers and LDS both limit it); queried once per instantiation
   static thread_local int cap = 0;

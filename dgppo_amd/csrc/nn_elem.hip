@@ -162,8 +162,8 @@ extern "C" int32_t dgppo_ln_relu_bwd(const float* x, const float* y, const float
 //   r = sig(gi_r + h Whr)  z = sig(gi_z + h Whz)  n = tanh(gi_n + r * (h Whn + bhn))  h' = (1 - z) n + z h
 // ---------------------------------------------------------------------------------------------------------------------
 #define GRU_H 64
-#define GRU_WL 193   // padded LDS row of Wh
-#define GRU_HL 65    // padded LDS row of h
+#define GRU_WL 194   // padded LDS row of the gate gradients: stride = 2 (mod 32) as well
+#define GRU_HL 66    // padded LDS row of h: stride = 2 (mod 32), conflict-free A-fragment reads (see nn_dense.hip)
 
 struct GruArgs {
   const float* gi;      // [rows, 192]

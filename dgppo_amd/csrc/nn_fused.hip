@@ -9,7 +9,7 @@
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define FZ_H 64            // hidden width of every layer in the chain
-#define FZ_HL 65           // LDS row stride (odd: conflict-free A-fragment reads)
+#define FZ_HL 66           // LDS row stride = 2 (mod 32): A-fragment reads touch banks (2 li + lq) mod 32, distinct in each half-wave (65 was 2-way: r03_nn_counters.json)
 #define FZ_RB 32           // rows per tile (2 row tiles of 16 per wave)
 #define FZ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
