@@ -190,6 +190,25 @@ __global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
   };
   auto epilogue = [&](int tile) {       // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
     const int row0 = tile * RB;
+    // the ReLU-mask values of the whole tile are read BEFORE the first store: read per element in the store loop, every
+    // load waits (vmcnt(0)) for the store in front of it as well — one serialised HBM round trip per element
+    float mk[RTW][NTW][4];
+    if (a.mask != nullptr) {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        int col = (cg + CG * t) * 16 + li;
+        col = col < N ? col : N - 1;
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int row = row0 + (rg * RTW + r) * 16 + lq * 4 + j;
+            row = row < a.M ? row : a.M - 1;
+            mk[r][t][j] = a.mask[(size_t)row * a.ldm + col];
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int col = (cg + CG * t) * 16 + li;
@@ -201,10 +220,8 @@ __global__ void __launch_bounds__(256) dense_fwd_kernel(DenseArgs a) {
           float v = acc[r][t][j] + bias[t];
           if constexpr (ACC) v += yold[r][t][j];
           if (a.act == 1) v = fmaxf(v, 0.0f);
-          if (col < N && row < a.M) {
-            if (a.mask != nullptr) v = (a.mask[(size_t)row * a.ldm + col] > 0.0f) ? v : 0.0f;
-            a.Y[(size_t)row * a.ldy + col] = v;
-          }
+          if (a.mask != nullptr) v = (mk[r][t][j] > 0.0f) ? v : 0.0f;
+          if (col < N && row < a.M) a.Y[(size_t)row * a.ldy + col] = v;
         }
       }
     }

@@ -201,6 +201,261 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))
   }
 }
 
+// ---- backward of the chain above: the three input gradients and the two LayerNorm+ReLU backward passes in ONE launch -----
+//   dy2 = dgi Wi^T,  dpre2 = LNReLU'(p2, y2, st2, g2; dy2),  dy1 = dpre2 W2^T,  dpre1 = LNReLU'(p1, y1, st1, g1; dy1),
+//   dx = dpre1 W1^T  (optionally masked by relu'(mask): the chain's input is a ReLU output for the per-agent networks)
+// (jax.grad through MLP + GRUCell input Dense, dgppo/nn/mlp.py:17-29, dgppo/nn/rnn.py:14-30, as taken by
+// dgppo/algo/informarl.py:377,440 and dgppo/algo/dgppo.py:316.)  It replaces five launches (dense^T, ln_relu_bwd, dense^T,
+// ln_relu_bwd, dense^T) and the two round trips of dy2 / dy1 through HBM; dpre2 / dpre1 are still written because the
+// weight gradients dW2 = y1^T dpre2, dW1 = x^T dpre1 (dgppo_dense_bwd_w) read them.  LayerNorm parameter gradients
+// (dgamma = sum dl xhat, dbeta = sum dl) are accumulated per workgroup and added with one atomic per column.
+// Same tiling as the forward: wave w owns columns 16w..16w+15 of every 64-wide result; W^T fragments (48 + 16 + 16
+// registers) stay resident; 32-row tiles; the dgi tile (192 wide) is staged in LDS, the next one prefetched in registers.
+struct MlpGiBwdArgs {
+  const float* dgi; int M;
+  const float *Wi, *W2, *W1, *g2, *g1;
+  const float *p2, *y2, *st2, *p1, *y1, *st1;
+  const float* mask; int ldm;
+  float *dpre2, *dpre1, *dx; int lddx;
+  float *dg2, *db2, *dg1, *db1;
+};
+#define FZ_GL 194          // LDS row stride of the dgi tile: = 2 (mod 32)
+#ifndef FZ_BWD_RT
+#define FZ_BWD_RT 1         // row tiles (of 16 rows) per wave in the backward chain
+#endif
+#ifndef FZ_BWD_WPE
+#define FZ_BWD_WPE 2
+#endif
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FZ_BWD_WPE, 8))) mlp_gi_bwd_kernel(MlpGiBwdArgs a) {
+  // 16-row tiles (ONE row tile per wave, the forward has two): the W^T fragments take 80 registers, every per-row quantity of
+  // the two LayerNorm backward passes is live next to them, and two row tiles spill
+  constexpr int BRT = FZ_BWD_RT, BRB = 16 * BRT;
+  extern __shared__ float sm[];
+  float* s_g = sm;                              // [RB][GL]  dgi rows
+  float* s_d2 = s_g + BRB * FZ_GL;            // [RB][HL]  dpre2
+  float* s_d1 = s_d2 + BRB * FZ_HL;           // [RB][HL]  dpre1
+  float* s_red = s_d1 + BRB * FZ_HL;          // [RB][8]   per-row (sum dxhat, sum dxhat xhat) of each of the 4 waves
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  const int c = w * 16 + li;
+  // B operands of X W^T: B[k][n] = W[n][k]; lane (li, lq) holds k = 4 kk + lq of output column n = c
+  float wi[48], w2[16], w1[16];
+#pragma unroll
+  for (int kk = 0; kk < 48; ++kk) wi[kk] = a.Wi[c * 192 + kk * 4 + lq];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { w2[kk] = a.W2[c * FZ_H + kk * 4 + lq]; w1[kk] = a.W1[c * FZ_H + kk * 4 + lq]; }
+  const float g2 = a.g2[c], g1 = a.g1[c];
+  float dgs[2] = {0.f, 0.f}, dbs[2] = {0.f, 0.f};     // this lane's partial sums of dgamma / dbeta: [layer 2, layer 1], column c
+  const int n_tiles = (a.M + BRB - 1) / BRB;
+  constexpr int GSL = BRB * 48 / 256;       // float4 slots of a dgi tile per lane
+  float4 gpf[GSL];
+  auto fetch = [&](int tile) {            // BRB rows x 48 float4; rows clamped
+#pragma unroll
+    for (int u = 0; u < GSL; ++u) {
+      const int idx = u * 256 + tid, r = idx / 48, q = idx - r * 48;
+      int row = tile * BRB + r;
+      row = row < a.M ? row : a.M - 1;
+      gpf[u] = *reinterpret_cast<const float4*>(a.dgi + (size_t)row * 192 + 4 * q);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < GSL; ++u) {
+      const int idx = u * 256 + tid, r = idx / 48, q = idx - r * 48;
+      float2* d = reinterpret_cast<float2*>(s_g + r * FZ_GL + 4 * q);
+      d[0] = make_float2(gpf[u].x, gpf[u].y); d[1] = make_float2(gpf[u].z, gpf[u].w);
+    }
+  };
+  // LayerNorm + ReLU backward for this lane's 8 elements (2 row tiles x 4 rows, column c).  v: dy in, dpre out.
+  auto ln_relu_bwd = [&](float (&v)[BRT][4], const float (&pv)[BRT][4], const float (&yv)[BRT][4], const float2 (&st)[BRT][4], float g,
+                         float& dg_acc, float& db_acc, float* s_out, float* d_out, int row0) {
+    float xh[BRT][4], dxh[BRT][4];
+#pragma unroll
+    for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = rt * 16 + lq * 4 + r;
+        int row = row0 + rl;
+        const bool ok = row < a.M;
+        row = ok ? row : a.M - 1;
+        const float2 ms = st[rt][r];
+        xh[rt][r] = (pv[rt][r] - ms.x) * ms.y;
+        const float dl = (ok && yv[rt][r] > 0.0f) ? v[rt][r] : 0.0f;
+        dg_acc += dl * xh[rt][r];
+        db_acc += dl;
+        dxh[rt][r] = dl * g;
+        const float s1 = row16_sum(dxh[rt][r]), s2 = row16_sum(dxh[rt][r] * xh[rt][r]);
+        if (li == 0) { float* d = s_red + rl * 8 + 2 * w; d[0] = s1; d[1] = s2; }
+        v[rt][r] = ms.y;                                  // keep rstd for the second half
+      }
+    FZ_LDS_BARRIER();
+#pragma unroll
+    for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = rt * 16 + lq * 4 + r;
+        const float4 p0 = *reinterpret_cast<const float4*>(s_red + rl * 8), p1 = *reinterpret_cast<const float4*>(s_red + rl * 8 + 4);
+        const float m1 = ((p0.x + p0.z) + (p1.x + p1.z)) * (1.0f / 64.0f);
+        const float m2 = ((p0.y + p0.w) + (p1.y + p1.w)) * (1.0f / 64.0f);
+        const float dp = v[rt][r] * (dxh[rt][r] - m1 - xh[rt][r] * m2);
+        v[rt][r] = dp;
+        s_out[rl * FZ_HL + c] = dp;
+        const int row = row0 + rl;
+        if (row < a.M) d_out[(size_t)row * FZ_H + c] = dp;
+      }
+    FZ_LDS_BARRIER();
+  };
+  auto load_st = [&](const float* src, int row0, float2 (&o)[BRT][4]) {        // (mean, rstd) of this lane's rows
+#pragma unroll
+    for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + rt * 16 + lq * 4 + r;
+        row = row < a.M ? row : a.M - 1;
+        o[rt][r] = reinterpret_cast<const float2*>(src)[row];
+      }
+  };
+  auto load8 = [&](const float* src, int ld, int row0, float (&o)[BRT][4]) {      // this lane's 8 elements of a [M, ld] matrix
+#pragma unroll
+    for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + rt * 16 + lq * 4 + r;
+        row = row < a.M ? row : a.M - 1;
+        o[rt][r] = src[(size_t)row * ld + c];
+      }
+  };
+  // the next tile's dgi rows are requested while the current tile computes (3 float4 per lane with 16-row tiles) and committed
+  // to LDS once every read of the current tile is retired (after the first barrier pair of the first LayerNorm backward)
+  int tile = blockIdx.x;
+  if (tile < n_tiles) { fetch(tile); commit(); }
+  __syncthreads();
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int row0 = tile * BRB;
+    const int nxt = tile + gridDim.x;
+    const bool more = nxt < n_tiles;
+    if (more) fetch(nxt);
+    // everything this tile reads from global memory is requested here, before the first GEMM: a load issued where it is
+    // needed costs a full memory round trip per LayerNorm stage (measured: 155 -> 139 -> see profiles/README.md)
+    float pv2[BRT][4], yv2[BRT][4], pv1[BRT][4], yv1[BRT][4], mk[BRT][4];
+    float2 sv2[BRT][4], sv1[BRT][4];
+    load8(a.p2, FZ_H, row0, pv2); load8(a.y2, FZ_H, row0, yv2); load_st(a.st2, row0, sv2);
+    load8(a.p1, FZ_H, row0, pv1); load8(a.y1, FZ_H, row0, yv1); load_st(a.st1, row0, sv1);
+    if (a.mask != nullptr) load8(a.mask, a.ldm, row0, mk);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[BRT];
+    float v[BRT][4];
+    // ---- dy2 = dgi Wi^T (K = 192) ----
+    for (int rt = 0; rt < BRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c0 = 0; c0 < 48; c0 += 8) {          // chunks of 8 k-steps: 16 A registers at a time (the kernel is register-bound)
+      float areg[BRT][8];
+#pragma unroll
+      for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) areg[rt][kk] = s_g[(rt * 16 + li) * FZ_GL + (c0 + kk) * 4 + lq];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int rt = 0; rt < BRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], wi[c0 + kk], acc[rt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[rt][r] = acc[rt][r];
+    // (the barriers inside ln_relu_bwd retire every read of s_g: the next tile's rows may be committed after it)
+    ln_relu_bwd(v, pv2, yv2, sv2, g2, dgs[0], dbs[0], s_d2, a.dpre2, row0);
+    if (more) commit();
+    // ---- dy1 = dpre2 W2^T ----
+    {
+      float areg[BRT][16];
+#pragma unroll
+      for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_d2[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+      __builtin_amdgcn_sched_barrier(0);
+      for (int rt = 0; rt < BRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int rt = 0; rt < BRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], w2[kk], acc[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[rt][r] = acc[rt][r];
+    ln_relu_bwd(v, pv1, yv1, sv1, g1, dgs[1], dbs[1], s_d1, a.dpre1, row0);
+    // ---- dx = dpre1 W1^T ----
+    {
+      float areg[BRT][16];
+#pragma unroll
+      for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) areg[rt][kk] = s_d1[(rt * 16 + li) * FZ_HL + kk * 4 + lq];
+      __builtin_amdgcn_sched_barrier(0);
+      for (int rt = 0; rt < BRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int rt = 0; rt < BRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[rt][kk], w1[kk], acc[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < BRT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + rt * 16 + lq * 4 + r;
+        float o = acc[rt][r];
+        if (a.mask != nullptr) o = (mk[rt][r] > 0.0f) ? o : 0.0f;
+        if (row < a.M) a.dx[(size_t)row * a.lddx + c] = o;
+      }
+    // (s_d1 is next written after two more barriers of the following tile: no hazard with the reads above)
+  }
+  // ---- LayerNorm parameter gradients: sum the 4 row groups of each column in LDS, one atomic per column and workgroup ----
+  __syncthreads();
+  float* red = sm;                                // [4 values][4 lq][64 columns]
+  red[(0 * 4 + lq) * 64 + c] = dgs[0]; red[(1 * 4 + lq) * 64 + c] = dbs[0];
+  red[(2 * 4 + lq) * 64 + c] = dgs[1]; red[(3 * 4 + lq) * 64 + c] = dbs[1];
+  __syncthreads();
+  {
+    const int which = tid >> 6, col = tid & 63;
+    const float tot = (red[(which * 4 + 0) * 64 + col] + red[(which * 4 + 1) * 64 + col]) +
+                      (red[(which * 4 + 2) * 64 + col] + red[(which * 4 + 3) * 64 + col]);
+    float* dst = which == 0 ? a.dg2 : (which == 1 ? a.db2 : (which == 2 ? a.dg1 : a.db1));
+    atomicAdd(dst + col, tot);
+  }
+}
+
+extern "C" int32_t dgppo_mlp_gi_bwd(const float* dgi, const float* Wi, const float* W2, const float* W1, const float* g2,
+                                    const float* g1, const float* p2, const float* y2, const float* st2, const float* p1,
+                                    const float* y1, const float* st1, const float* relu_mask, int32_t ldm, float* dpre2,
+                                    float* dpre1, float* dx, int32_t lddx, float* dg2, float* db2, float* dg1, float* db1,
+                                    int32_t M, void* stream) {
+  DGPPO_REQUIRE(M >= 0 && lddx >= FZ_H && (relu_mask == nullptr || ldm >= FZ_H), "mlp_gi_bwd: bad shape M=%d lddx=%d ldm=%d", M, lddx, ldm);
+  DGPPO_REQUIRE(dgi && Wi && W2 && W1 && g2 && g1 && p2 && y2 && st2 && p1 && y1 && st1 && dpre2 && dpre1 && dx && dg2 && db2 &&
+                dg1 && db1, "mlp_gi_bwd: NULL operand");
+  DGPPO_REQUIRE((reinterpret_cast<uintptr_t>(dgi) & 15) == 0, "mlp_gi_bwd: dgi must be 16-byte aligned");
+  if (M == 0) return 0;
+  MlpGiBwdArgs a{dgi, M, Wi, W2, W1, g2, g1, p2, y2, st2, p1, y1, st1, relu_mask, ldm, dpre2, dpre1, dx, lddx, dg2, db2, dg1, db1};
+  constexpr int BRB = 16 * FZ_BWD_RT;
+  const size_t smem_t = sizeof(float) * (BRB * FZ_GL + 2 * BRB * FZ_HL + BRB * 8), smem_r = sizeof(float) * 16 * 64;
+  const size_t smem = smem_t > smem_r ? smem_t : smem_r;   // the final reduction of the LayerNorm gradients reuses the buffer
+  static thread_local int cap = 0;
+  if (cap == 0) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&mlp_gi_bwd_kernel), 256, smem) !=
+            hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cap = per_cu * cus;
+  }
+  const int tiles = (M + BRB - 1) / BRB;
+  hipLaunchKernelGGL(mlp_gi_bwd_kernel, dim3(tiles < cap ? tiles : cap), dim3(256), smem, (hipStream_t)stream, a);
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1, const float* b1, const float* g1,
                                     const float* be1, const float* W2, const float* b2, const float* g2, const float* be2,
                                     const float* Wi, const float* bi, float* p1, float* y1, float* st1, float* p2, float* y2,

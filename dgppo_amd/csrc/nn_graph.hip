@@ -1310,6 +1310,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DGPPO_
 #pragma unroll
         for (int ft = 0; ft < FT; ++ft) dxacc[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ct], bq[k4][ft], dxacc[ct][ft], 0, 0, 0);
     }
+    // Epilogue in two passes.  What every output element still needs from memory — the direct x_i part of dzcat for an agent
+    // row, the sign of the node's own feature for the ReLU mask of another row — is READ FOR ALL ELEMENTS FIRST and the stores
+    // follow.  Interleaved (load, use, store per element) the compiler must keep program order between a store and the next
+    // load (the pointers may alias) and `s_waitcnt vmcnt(0)` before each use also waits for every earlier STORE: 40 fully
+    // serialised memory round trips per graph, 60 % of the kernel's wave time (SQ_WAIT_ANY, profiles/r03_nn_counters.json).
+    float side[CT][FT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = ct * 16 + lq * 4 + r;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          const int f = ft * 16 + li;
+          float sv = 1.0f;
+          if (node < Ns && f < F) {
+            if (node < n) sv = dzc[node * Kp + f];
+            else if (a.dXo != nullptr && a.relu_xo) sv = a.Xo[((size_t)g * (Ns - n) + (node - n)) * F + f];   // just read as a fragment: an L2 hit
+          }
+          side[ct][ft][r] = sv;
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -1319,11 +1342,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DGPPO_
         for (int ft = 0; ft < FT; ++ft) {
           const int f = ft * 16 + li;
           if (node >= Ns || f >= F) continue;
-          if (node < n) a.dXa[((size_t)g * n + node) * F + f] = dxacc[ct][ft][r] + dzc[node * Kp + f];
+          if (node < n) a.dXa[((size_t)g * n + node) * F + f] = dxacc[ct][ft][r] + side[ct][ft][r];
           else if (a.dXo != nullptr) {
             const size_t o = ((size_t)g * (Ns - n) + (node - n)) * F + f;
             float v = dxacc[ct][ft][r];
-            if (a.relu_xo) v = (a.Xo[o] > 0.0f) ? v : 0.0f;     // the node row was just read as an MFMA fragment: an L2 hit
+            if (a.relu_xo) v = (side[ct][ft][r] > 0.0f) ? v : 0.0f;
             a.dXo[o] = v;
           }
         }

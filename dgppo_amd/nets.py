@@ -392,6 +392,11 @@ class Net:
         feats: GraphFeats = act["feats"]
         Ro = G * feats.n_other
         feat = act["feat"]
+        # the MLP trunk + GRU input projection ran as the fused forward kernel (64-wide chain, one GRU layer): its backward chain
+        # is fused as well (DGPPO_NO_FUSED_TRUNK_BWD=1: the separate launches, for A/B runs and as the tests' second opinion)
+        fused_trunk = (self.rnn == "gru" and self.rnn_layers == 1 and self.kind != "Vhg" and dout.is_cuda
+                       and os.environ.get("DGPPO_NO_FUSED_TRUNK_BWD") is None)
+        dgi0 = None
         dhs = A.get(f"{tag}.dhs", Rh, HID)
         if self.kind == "policy":
             K.dense_bwd_w(act["u"], dout, self.g("head.Wms"), self.g("head.bms"))
@@ -430,13 +435,27 @@ class Net:
                 K.dense_bwd_w(st["hprev"], dgh[:, 2 * HID:], self.g(f"{pre}.Wh")[:, 2 * HID:], self.g(f"{pre}.bhn"))
                 x_l = act["y2"] if l == 0 else st["x"]
                 K.dense_bwd_w(x_l, dgi, self.g(f"{pre}.Wi"), self.g(f"{pre}.bi"))
+                if l == 0 and fused_trunk:
+                    dgi0 = dgi                         # the fused trunk backward below starts from the gate-input gradient
+                    break
                 dx = A.get(f"{tag}.dy" if l == 0 else f"{tag}.dx{l}", Rh, HID)
                 K.dense_fwd(dgi, self.p(f"{pre}.Wi"), None, dx, trans_w=True)
                 dhs = dx                               # gradient of the layer below's output sequence
             dy = dhs
         x_in = {1: act["mlp_in"], 2: act["y1"]}
         top = act[f"Xa{self.gnn_layers}"]          # output of the last GNN layer (a ReLU output): masks the gradient entering it
-        for i in (2, 1):
+        if fused_trunk:
+            # dgi -> (Wi^T) -> LN+ReLU' -> (W2^T) -> LN+ReLU' -> (W1^T) -> dx in ONE launch (dgppo_mlp_gi_bwd): five launches and two
+            # [Rh, 64] round trips through HBM less per network; the two weight gradients read the dpre buffers it writes
+            dpre2, dpre1 = A.get(f"{tag}.dpre2", Rh, HID), A.get(f"{tag}.dpre1", Rh, HID)
+            dy = A.get(f"{tag}.dyy1", Rh, HID)
+            K.mlp_gi_bwd(dgi0, self.p("gru.Wi"), self.p("mlp.W2"), self.p("mlp.W1"), self.p("mlp.g2"), self.p("mlp.g1"),
+                         act["p2"], act["y2"], act["st2"], act["p1"], act["y1"], act["st1"],
+                         top if self.kind in ("policy", "Vh") else None, dpre2, dpre1, dy,
+                         self.g("mlp.g2"), self.g("mlp.be2"), self.g("mlp.g1"), self.g("mlp.be1"))
+            K.dense_bwd_w(x_in[2], dpre2, self.g("mlp.W2"), self.g("mlp.b2"))
+            K.dense_bwd_w(x_in[1], dpre1, self.g("mlp.W1"), self.g("mlp.b1"))
+        for i in (() if fused_trunk else (2, 1)):
             dpre = A.get(f"{tag}.dpre{i}", Rh, HID)
             K.ln_relu_bwd(act[f"p{i}"], act[f"y{i}"], act[f"st{i}"], self.p(f"mlp.g{i}"), dy, dpre, self.g(f"mlp.g{i}"),
                           self.g(f"mlp.be{i}"))

@@ -74,6 +74,28 @@ def mlp_gi_fwd(X, W1, b1, g1, be1, W2, b2, g2, be2, Wi, bi, gi, saves=None):
     N.check(rc, "dgppo_mlp_gi_fwd")
 
 
+def mlp_gi_bwd(dgi, Wi, W2, W1, g2, g1, p2, y2, st2, p1, y1, st1, relu_mask, dpre2, dpre1, dx, dg2, db2, dg1, db1):
+    """activation gradients of the mlp_gi_fwd chain in one kernel (dgppo_mlp_gi_bwd): dgi [M,192] -> dpre2, dpre1, dx [M,64];
+    dg* / db* [64] accumulate the LayerNorm parameter gradients; relu_mask [M,64] or None masks dx."""
+    M = dgi.shape[0]
+    N.expect_shape(dgi, (M, 192), "dgi")
+    for t, shp, nm in ((Wi, (64, 192), "Wi"), (W2, (64, 64), "W2"), (W1, (64, 64), "W1"), (g2, (64,), "g2"), (g1, (64,), "g1"),
+                       (p2, (M, 64), "p2"), (y2, (M, 64), "y2"), (st2, (M, 2), "st2"), (p1, (M, 64), "p1"), (y1, (M, 64), "y1"),
+                       (st1, (M, 2), "st1"), (dpre2, (M, 64), "dpre2"), (dpre1, (M, 64), "dpre1"), (dx, (M, 64), "dx"),
+                       (dg2, (64,), "dg2"), (db2, (64,), "db2"), (dg1, (64,), "dg1"), (db1, (64,), "db1")):
+        N.expect_shape(t, shp, nm)
+    mp, ldm = (None, 0)
+    if relu_mask is not None:
+        mp, ldm, Mm, Km = _mat(relu_mask, "relu_mask")
+        if (Mm, Km) != (M, 64):
+            raise ValueError(f"mlp_gi_bwd: relu_mask must be [M, 64], got {tuple(relu_mask.shape)}")
+    FLOPS[0] += 2.0 * M * (64 * 64 * 2 + 64 * 192)
+    rc = N.lib().dgppo_mlp_gi_bwd(_p(dgi), _p(Wi), _p(W2), _p(W1), _p(g2), _p(g1), _p(p2), _p(y2), _p(st2), _p(p1), _p(y1), _p(st1),
+                                  mp if mp is not None else C.c_void_p(0), ldm, _p(dpre2), _p(dpre1), _p(dx), 64,
+                                  _p(dg2), _p(db2), _p(dg1), _p(db1), M, N.stream_ptr())
+    N.check(rc, "dgppo_mlp_gi_bwd")
+
+
 def gru1_head_fwd(gi, Wh, bhn, h0, W1, b1, W2, b2, hs, hprev, gates, u, out):
     """one GRU step (T = 1) + head Dense(s): out = (h' W1 + b1) [W2 + b2]; see dgppo_gru1_head_fwd in the header."""
     M = gi.shape[0]

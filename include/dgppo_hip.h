@@ -203,6 +203,16 @@ int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1, const flo
                          const float* W2, const float* b2, const float* g2, const float* be2, const float* Wi,
                          const float* bi, float* p1, float* y1, float* st1, float* p2, float* y2, float* st2, float* gi,
                          int32_t M, void* stream);
+/* Backward of that chain with respect to its activations, in one launch (jax.grad through dgppo/nn/mlp.py:17-29 and the
+ * GRUCell input Dense of dgppo/nn/rnn.py:14-30, as taken by dgppo/algo/informarl.py:377,440 / dgppo/algo/dgppo.py:316):
+ * dpre2 = LNReLU'(p2, y2, st2, g2; dgi Wi^T), dpre1 = LNReLU'(p1, y1, st1, g1; dpre2 W2^T), dx = dpre1 W1^T, where
+ * LNReLU'(p, y, st, g; dy) = rstd (dxh - mean(dxh) - xhat mean(dxh xhat)), dxh = dy (y > 0) g.  relu_mask [M, ldm] (may be
+ * NULL): dx = (mask > 0) ? dx : 0.  dpre2 / dpre1 [M,64] are outputs (the weight gradients dW2 = y1^T dpre2, dW1 = X^T dpre1
+ * read them); dg2/db2/dg1/db1 [64] += the LayerNorm scale / bias gradients.  dgi [M,192] 16-byte aligned.          */
+int32_t dgppo_mlp_gi_bwd(const float* dgi, const float* Wi, const float* W2, const float* W1, const float* g2,
+                         const float* g1, const float* p2, const float* y2, const float* st2, const float* p1,
+                         const float* y1, const float* st1, const float* relu_mask, int32_t ldm, float* dpre2, float* dpre1,
+                         float* dx, int32_t lddx, float* dg2, float* db2, float* dg1, float* db1, int32_t M, void* stream);
 /* The same weight gradient with its second stage DEFERRED: only the partial-slab kernel is launched; *pending describes the
  * reduction that is still owed (pending->pending = 0 when the call needed none).  The caller owns the descriptors and the
  * workspace REGION of every deferred call until it has flushed them with dgppo_dense_bwd_w_reduce_batch (one launch per

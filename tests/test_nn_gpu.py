@@ -139,6 +139,58 @@ def test_mlp_gi_fused(cuda, M, save, strided):
             _close(got, want, 2e-5, nm)
 
 
+@pytest.mark.parametrize("M,masked", [(1, False), (45, True), (1000, False), (33000, True)])
+def test_mlp_gi_bwd_fused(cuda, M, masked):
+    """dgppo_mlp_gi_bwd (dense^T -> LN+ReLU backward -> dense^T -> LN+ReLU backward -> dense^T in one launch) against autograd of
+    the plain torch fp32 composition (jax.grad through mlp.py:17-29 / rnn.py:14-30), and against the five unfused launches it
+    replaces; ragged M, with and without the ReLU mask on dx."""
+    from dgppo_amd import ops_nn as K_
+    g = torch.Generator().manual_seed(M + 3)
+    X = torch.randn(M, 64, generator=g).requires_grad_()
+    P = {k: (torch.randn(*shp, generator=g) * sc) for k, shp, sc in (
+        ("W1", (64, 64), 0.2), ("b1", (64,), 0.1), ("g1", (64,), 1.0), ("be1", (64,), 0.1), ("W2", (64, 64), 0.2),
+        ("b2", (64,), 0.1), ("g2", (64,), 1.0), ("be2", (64,), 0.1), ("Wi", (64, 192), 0.2), ("bi", (192,), 0.1))}
+    for k in ("g1", "be1", "g2", "be2"):
+        P[k].requires_grad_()
+
+    def ln(v, gam, bet):
+        mean = v.mean(-1, keepdim=True)
+        var = ((v * v).mean(-1, keepdim=True) - mean * mean).clamp_min(0.0)
+        rstd = torch.rsqrt(var + 1e-6)
+        return (v - mean) * rstd * gam + bet, mean, rstd
+    p1 = X @ P["W1"] + P["b1"]; p1.retain_grad()
+    o1, m1, r1 = ln(p1, P["g1"], P["be1"]); y1 = torch.relu(o1)
+    p2 = y1 @ P["W2"] + P["b2"]; p2.retain_grad()
+    o2, m2, r2 = ln(p2, P["g2"], P["be2"]); y2 = torch.relu(o2)
+    gi = y2 @ P["Wi"] + P["bi"]
+    dgi = torch.randn(M, 192, generator=g)
+    gi.backward(dgi)
+    mask = torch.randn(M, 64, generator=g) if masked else None
+    want_dx = X.grad * (mask > 0) if masked else X.grad
+    d = lambda t: t.detach().to(cuda).contiguous()
+    outs = {k: torch.full((M, 64), float("nan"), device=cuda) for k in ("dpre2", "dpre1", "dx")}
+    pg = {k: torch.zeros(64, device=cuda) for k in ("dg2", "db2", "dg1", "db1")}
+    K_.mlp_gi_bwd(d(dgi), d(P["Wi"]), d(P["W2"]), d(P["W1"]), d(P["g2"]), d(P["g1"]), d(p2), d(y2), d(torch.cat([m2, r2], 1)),
+                  d(p1), d(y1), d(torch.cat([m1, r1], 1)), d(mask) if masked else None, outs["dpre2"], outs["dpre1"], outs["dx"],
+                  pg["dg2"], pg["db2"], pg["dg1"], pg["db1"])
+    _close(outs["dpre2"], p2.grad, 2e-5, "dpre2")
+    _close(outs["dpre1"], p1.grad, 2e-5, "dpre1")
+    _close(outs["dx"], want_dx, 2e-5, "dx")
+    for k, want in (("dg2", P["g2"].grad), ("db2", P["be2"].grad), ("dg1", P["g1"].grad), ("db1", P["be1"].grad)):
+        _close(pg[k], want, 3e-5, k)
+    # the unfused sequence of launches gives the same numbers
+    dy = torch.empty(M, 64, device=cuda); dp2 = torch.empty(M, 64, device=cuda); dp1 = torch.empty(M, 64, device=cuda)
+    dxu = torch.empty(M, 64, device=cuda)
+    ug = {k: torch.zeros(64, device=cuda) for k in ("dg2", "db2", "dg1", "db1")}
+    K_.dense_fwd(d(dgi), d(P["Wi"]), None, dy, trans_w=True)
+    K_.ln_relu_bwd(d(p2), d(y2), d(torch.cat([m2, r2], 1)), d(P["g2"]), dy, dp2, ug["dg2"], ug["db2"])
+    K_.dense_fwd(dp2, d(P["W2"]), None, dy, trans_w=True)
+    K_.ln_relu_bwd(d(p1), d(y1), d(torch.cat([m1, r1], 1)), d(P["g1"]), dy, dp1, ug["dg1"], ug["db1"])
+    K_.dense_fwd(dp1, d(P["W1"]), None, dxu, trans_w=True, relu_mask=d(mask) if masked else None)
+    _close(outs["dx"], dxu.cpu(), 2e-5, "dx vs unfused")
+    _close(outs["dpre2"], dp2.cpu(), 2e-5, "dpre2 vs unfused")
+
+
 @pytest.mark.parametrize("M,two,use_h0,save", [(1, True, True, True), (45, False, False, False), (1000, True, False, True),
                                                (33000, False, True, True), (33000, True, True, False)])
 def test_gru1_head_fused(cuda, M, two, use_h0, save):

@@ -47,6 +47,13 @@ if which in ("all", "dense"):
                             (R, 8, 24, False), (Ro, 8, 32, False), (R, 64, 144, True), (R, 192, 64, True), (R, 64, 64, True),
                             (R, 64, 4, False), (R, 4, 64, True), (R, 1, 64, True), (32768, 8, 24, False), (32768, 144, 64, False), (32768, 64, 64, False), (32768, 64, 192, False)]:
         dense_case(M, Kd, Nd, tr)
+if which in ("all", "dense", "densemask"):
+    # the ReLU-masked input gradients of the update: dX = (mask > 0) ? dY @ W^T : 0
+    for (M, Kd, Nd) in [(R, 64, 64), (R, 192, 64), (R, 64, 144), (Ro, 32, 32)]:
+        X = torch.randn(M, Kd, device=dev); W = torch.randn(Nd, Kd, device=dev); Y = torch.empty(M, Nd, device=dev)
+        mk = torch.randn(M, Nd, device=dev)
+        timeit(f"dense_fwd masked M={M} K={Kd} N={Nd} trans=1", lambda: K.dense_fwd(X, W, None, Y, trans_w=True, relu_mask=mk),
+               flops=2.0 * M * Kd * Nd, bytes_=4.0 * M * (Kd + 2 * Nd))
 if which in ("all", "elem"):
     x = torch.randn(R, 64, device=dev); g = torch.ones(64, device=dev); b = torch.zeros(64, device=dev)
     y = torch.empty_like(x); st = torch.empty(R, 2, device=dev); dx = torch.empty_like(x)
@@ -73,6 +80,8 @@ if which in ("all", "attn"):
             timeit(f"attn_fwd G={G} F={F}", lambda: K.attn_fwd(cfg, F, 3, Kp, qt, Xa, Xo, ef, em, z, at, G))
             dq = torch.empty_like(qt); dXa = torch.empty_like(Xa); dXo = torch.empty_like(Xo)
             timeit(f"attn_bwd G={G} F={F}", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, dXa, dXo, G))
+            if F == 32:   # how much of the wide backward is the input gradient (dXs: 160 of its 320 MFMAs, 10 KB of stores per graph)
+                timeit(f"attn_bwd G={G} F={F} (dqt only)", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, None, None, G))
             if F == 8:    # the first layer needs no input gradient
                 timeit(f"attn_bwd G={G} F={F} (dqt only)", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, None, None, G))
 if which in ("all", "fused"):
@@ -82,6 +91,25 @@ if which in ("all", "fused"):
         gi = torch.empty(M, 192, device=dev)
         sv = tuple(torch.empty(M, w, device=dev) for w in (64, 64, 2, 64, 64, 2)) if train else None
         timeit(f"mlp_gi_fwd M={M} train={train}", lambda: K.mlp_gi_fwd(X, *P, gi, sv))
+if which in ("all", "fusedbwd"):
+    for M in (131072, 16384):
+        P = [torch.randn(*s_, device=dev) * 0.1 for s_ in ((64, 192), (64, 64), (64, 64), (64,), (64,))]
+        dgi = torch.randn(M, 192, device=dev)
+        A = [torch.randn(M, w, device=dev) for w in (64, 64, 2, 64, 64, 2)]
+        mask = torch.randn(M, 64, device=dev)
+        o = [torch.empty(M, 64, device=dev) for _ in range(3)]
+        pg = [torch.zeros(64, device=dev) for _ in range(4)]
+        timeit(f"mlp_gi_bwd fused M={M}", lambda: K.mlp_gi_bwd(dgi, P[0], P[1], P[2], P[3], P[4], A[3], A[4], A[5], A[0], A[1], A[2], mask,
+                                                               o[0], o[1], o[2], *pg))
+        dy = torch.empty(M, 64, device=dev)
+
+        def unfused():
+            K.dense_fwd(dgi, P[0], None, dy, trans_w=True)
+            K.ln_relu_bwd(A[3], A[4], A[5], P[3], dy, o[0], pg[0], pg[1])
+            K.dense_fwd(o[0], P[1], None, dy, trans_w=True)
+            K.ln_relu_bwd(A[0], A[1], A[2], P[4], dy, o[1], pg[2], pg[3])
+            K.dense_fwd(o[1], P[2], None, o[2], trans_w=True, relu_mask=mask)
+        timeit(f"mlp bwd chain unfused (5 launches) M={M}", unfused)
 if which in ("all", "tail"):
     for M, two, train in ((32768, True, False), (131072, False, True), (524288, False, False)):
         gi = torch.randn(M, 192, device=dev); h0 = torch.randn(M, 64, device=dev)
