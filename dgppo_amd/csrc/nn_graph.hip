@@ -12,6 +12,7 @@
 // features, and the matching backward.  const(i,h) (the key bias) cancels in the softmax.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct Topo {
   int n, ng, gs, os, per, lidar, spread;  // per = k (LiDAR) or n_obs (MPE)
@@ -1354,6 +1355,590 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DGPPO_
   }
 }
 
+// ---- F = 32, block-diagonal form (one wave per graph) -----------------------------------------------------------
+// The dense wave kernels above form the whole [n*H x nodes] logit tile although an agent only attends to the nodes every
+// agent sees (agents, goals: "shared") and to its OWN 8 LiDAR hit nodes: 4/5 of the tile's columns (LidarSpread n = 8: 64
+// of 80) are used by one agent in eight.  Here the wave is laid out as 8 lanes per AGENT (il = lane / 8, sub = lane & 7):
+//   * lane (il, sub) owns, for every head, the slots  {shared node p * 8 + sub, p < PS}  and  {hit sub}  of agent il, i.e.
+//     all S slots of an agent live in its 8 lanes (PS + 1 registers per head) and the softmax is a register / DPP matter;
+//   * all products run on the matrix cores as v_mfma_f32_4x4x1 (16 independent 4x4 blocks, one k per instruction): block
+//     (il, g2 = bit 2 of the lane), A rows = the 4 heads of agent il, B columns = 4 nodes (logits, dA) or 4 feature quads
+//     (aggregation, dQt).  A block only ever multiplies what its agent needs: 96 + 96 small MFMAs (1.5 k SIMD cycles) per
+//     graph forward instead of 160 16x16x4 tiles (5.1 k), 2.7 k instead of 10.2 k backward;
+//   * every global row is read ONCE, as coalesced 16-byte pieces, into a padded LDS image (shared rows, the 64 hit rows of
+//     the agent batch, query / dZ rows) from which all operand layouts are read; the dense kernels re-read the node rows
+//     from global memory per layout (2.4x the algorithmic bytes, profiles/r03_nn_counters.json).
+// More than 8 agents: batches of 8 agents run one after the other over the same staged shared rows.
+// Requirements (else the dense kernels above): F = 32, H <= 4, LiDAR hits 8 per agent (or no private nodes at all), at most
+// 32 shared nodes.  Same arithmetic as gnn.py:85-117 up to the summation order.
+#define ABD_XL 36                      // LDS row stride of a staged 32-float row (16-byte aligned, conflict-free b128 row reads)
+#define ABD_DZL 40                     // the staged dZ rows carry the 4 edge-feature gradients behind the 32 features
+typedef float4 abd_f4;
+__device__ inline f32x4g mfma4(float a_, float b_, f32x4g c_) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a_, b_, c_, 0, 0, 0); }
+__device__ inline const float* f4e(const float4& v) { return reinterpret_cast<const float*>(&v); }
+__device__ inline float4 ld4_if(bool ok, const float4* p) {      // predicated 16-byte load, zeros otherwise
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) v = *p;
+  return v;
+}
+
+// An opaque zero that DEPENDS on loaded values (v_and_b32 with 0 behind an asm the optimiser cannot see through): added to the
+// LDS addresses of the staging writes it ties the loads of the small operands (masks, edge features, attention weights ...)
+// to the first trip to memory.  Left alone the scheduler sinks them into the first MFMA phase and the wave pays a second trip;
+// a side-effecting fence (sched_barrier, asm volatile) at that place makes the compiler keep the staging arrays in scratch.
+__device__ inline int opaque_zero(int bits) {
+  asm("v_and_b32 %0, 0, %0" : "+v"(bits));
+  return bits;
+}
+__device__ inline int f4bits(const float4& v) { return __float_as_int(v.x) | __float_as_int(v.y) | __float_as_int(v.z) | __float_as_int(v.w); }
+
+template <int PS, bool HITS> struct AbdLds {
+  static constexpr int NSP = PS * 8, PC = NSP + (HITS ? 8 : 0), PL = PC + 4;
+  static constexpr int XS = NSP * ABD_XL, XH = HITS ? 64 * ABD_XL + 64 : 0;
+  static constexpr int QP = (32 * ABD_XL > 32 * PL) ? 32 * ABD_XL : 32 * PL;      // query rows, later the P tile [32][PL]
+  static constexpr int FWD = XS + XH + QP;
+  static constexpr int DZ = 32 * ABD_DZL, PTL = NSP + 1, PT = 32 * PTL, DL = 32 * PL;
+  static constexpr int BWD = XS + XH + DZ + PT + DL;
+};
+
+template <int PS, bool HITS, int AB>
+__global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
+  extern __shared__ float4 abd_sm[];
+  using L = AbdLds<PS, HITS>;
+  constexpr int F = 32, NSP = L::NSP, PC = L::PC, PL = L::PL, NPR = PS + (HITS ? 1 : 0), Wd = F + 4;
+  const Topo& t = a.t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 2 + wave);
+  if (g >= a.G) return;                                        // no barriers below
+  const int n = t.n, S = t.S, Ns = t.Ns, H = a.H, Kp = a.Kp;
+  const int NSH = HITS ? t.n + t.ng : Ns;
+  const int kc = F + H * Wd;
+  float* XS = reinterpret_cast<float*>(abd_sm) + wave * L::FWD;
+  float* XH = XS + L::XS;
+  float* QP = XH + L::XH;
+  const float4* Xa4 = reinterpret_cast<const float4*>(a.Xa + (size_t)g * n * F);
+  const float4* Xo4 = reinterpret_cast<const float4*>(a.Xo + (size_t)g * (Ns - n) * F);
+  const float4* qt4 = reinterpret_cast<const float4*>(a.qt + (size_t)g * n * H * F);
+  float* zc = a.zcat + (size_t)g * n * Kp;
+  const int il = lane >> 3, sub = lane & 7, g2 = (lane >> 2) & 1, c = lane & 3, hA = lane & 3;
+  // ---- every global read is requested before anything waits: rows are fetched unconditionally from clamped addresses (a
+  //      pad row duplicates a real one; it only ever meets zeros of P), so there is no branch around a load and the wave
+  //      makes ONE trip to memory per agent batch ----
+  float4 vs[PS];
+#pragma unroll
+  for (int p = 0; p < PS; ++p) {
+    const int row = p * 8 + il;
+    const int ra = row < n ? row : n - 1, ro = (row < NSH ? row : NSH - 1) - n;
+    const float4* src = (row < n || NSH == n) ? Xa4 + ra * 8 + sub : Xo4 + ro * 8 + sub;
+    vs[p] = *src;
+  }
+  const float* mk = a.emask + (size_t)g * n * S;
+  const float4* ef4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
+  float* at = a.attn + (size_t)g * n * S * H;
+#pragma unroll
+  for (int ab = 0; ab < AB; ++ab) {       // AB = ceil(n / 8), a compile-time count: straight-line code, every array in registers
+    const int i = ab * 8 + il;
+    const bool live = i < n;
+    const int ic = live ? i : n - 1;
+    float4 vh[HITS ? 8 : 1], vq[4];
+    if constexpr (HITS) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int hb = ab * 64 + k * 8 + il;
+        hb = hb < n * 8 ? hb : n * 8 - 1;
+        vh[k] = Xo4[(t.ng + hb) * 8 + sub];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = k * 8 + il;
+      int ri = ab * 8 + (row >> 2), rh = row & 3;
+      ri = ri < n ? ri : n - 1; rh = rh < H ? rh : H - 1;
+      vq[k] = qt4[(ri * H + rh) * 8 + sub];
+    }
+    // the lane's slots: mask and edge features
+    int slot[NPR];
+    float mkv[NPR];
+    float4 efv[NPR];
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) {
+      int sl;
+      if (HITS && p == PS) sl = n + t.gs + sub;
+      else { const int j = p * 8 + sub; sl = (j < NSH) ? slot_of(t, j, ic) : -1; }
+      slot[p] = live ? sl : -1;
+      const int sc = sl < 0 ? 0 : sl;
+      mkv[p] = mk[ic * S + sc];
+      efv[p] = ef4[ic * S + sc];
+    }
+    int pin = 0;
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) pin |= __float_as_int(mkv[p]) | f4bits(efv[p]);
+    const int pin0 = opaque_zero(pin);
+    if (ab == 0) {
+#pragma unroll
+      for (int p = 0; p < PS; ++p) *reinterpret_cast<float4*>(XS + pin0 + (p * 8 + il) * ABD_XL + sub * 4) = vs[p];
+    }
+    if constexpr (HITS) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(XH + pin0 + (k * 8 + il) * ABD_XL + k * 8 + sub * 4) = vh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(QP + pin0 + (k * 8 + il) * ABD_XL + sub * 4) = vq[k];
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) mkv[p] = (slot[p] >= 0) ? mkv[p] : 0.0f;
+    // ---- logits: A = the query row of (agent il, head hA), B = the lane's own node rows ----
+    f32x4g acc[NPR];
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) acc[p] = f32x4g{0.f, 0.f, 0.f, 0.f};
+    {
+      const float* qrow = QP + (il * 4 + hA) * ABD_XL;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(qrow + k * 4);
+        float4 x[NPR];
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) {
+          if (HITS && p == PS) x[p] = *reinterpret_cast<const float4*>(XH + lane * ABD_XL + il * 8 + k * 4);
+          else x[p] = *reinterpret_cast<const float4*>(XS + (p * 8 + sub) * ABD_XL + k * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int p = 0; p < NPR; ++p) acc[p] = mfma4(f4e(q)[u], f4e(x[p])[u], acc[p]);
+      }
+    }
+    // ---- masked softmax per head over the 8 lanes x NPR registers of the agent; edge aggregation; P -> LDS ----
+    float* PT = QP;                                            // DS operations of a wave execute in order: the query rows are read
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (h < H) {
+        float l[NPR];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) { l[p] = (mkv[p] != 0.0f) ? acc[p][h] : -INFINITY; mx = fmaxf(mx, l[p]); }
+        mx = grp8_max(mx);
+        float den = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) { l[p] = (l[p] == -INFINITY) ? 0.0f : __expf(l[p] - mx); den += l[p]; }
+        den = grp8_sum(den);
+        const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) {
+          const float av = l[p] * inv;
+          acc[p][h] = av;
+          if (slot[p] >= 0) {
+            if (a.attn != nullptr) at[(i * S + slot[p]) * H + h] = av;
+            if (av != 0.0f) {   // masked slots may carry 5e5 / NaN edge features: skip, never multiply
+              const float4 e = efv[p];
+              z0 = fmaf(av, e.x, z0); z1 = fmaf(av, e.y, z1); z2 = fmaf(av, e.z, z2); z3 = fmaf(av, e.w, z3);
+            }
+          }
+        }
+        z0 = grp8_sum(z0); z1 = grp8_sum(z1); z2 = grp8_sum(z2); z3 = grp8_sum(z3);
+        if (live && sub == 0) *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + F) = make_float4(z0, z1, z2, z3);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) acc[p][h] = 0.0f;
+      }
+#pragma unroll
+      for (int p = 0; p < NPR; ++p) PT[(il * 4 + h) * PL + p * 8 + sub] = acc[p][h];
+    }
+    // ---- Zx = P Xs: A = row (il, hA) of P, B = feature quad (g2 * 4 + c) of the node of the k-step ----
+    {
+      float pa[PC];
+#pragma unroll
+      for (int k = 0; k < PC / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(PT + (il * 4 + hA) * PL + k * 4);
+        pa[k * 4] = v.x; pa[k * 4 + 1] = v.y; pa[k * 4 + 2] = v.z; pa[k * 4 + 3] = v.w;
+      }
+      f32x4g az[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) az[q] = f32x4g{0.f, 0.f, 0.f, 0.f};
+      const int fq = (g2 * 4 + c) * 4;
+#pragma unroll
+      for (int kk = 0; kk < NSP; ++kk) {
+        const float4 b = *reinterpret_cast<const float4*>(XS + kk * ABD_XL + fq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) az[q] = mfma4(pa[kk], f4e(b)[q], az[q]);
+      }
+      if constexpr (HITS) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float4 b = *reinterpret_cast<const float4*>(XH + (il * 8 + m) * ABD_XL + il * 8 + fq);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) az[q] = mfma4(pa[NSP + m], f4e(b)[q], az[q]);
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (h < H) *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + fq) = make_float4(az[0][h], az[1][h], az[2][h], az[3][h]);
+      }
+    }
+  }
+  // the parts of zcat that are plain copies: x_i (from its staged image), the constant column, zero padding
+#pragma unroll
+  for (int p = 0; p < PS; ++p) {
+    const int row = p * 8 + il;
+    if (row < n) *reinterpret_cast<float4*>(zc + row * Kp + sub * 4) = *reinterpret_cast<const float4*>(XS + row * ABD_XL + sub * 4);
+  }
+  {
+    const int wpad = Kp - kc;                                  // >= 1: the constant column, then zeros
+    for (int i = lane; i < n; i += 64)
+      for (int cc = 0; cc < wpad; ++cc) zc[i * Kp + kc + cc] = (cc == 0) ? 1.0f : 0.0f;
+  }
+}
+
+// backward of the block-diagonal form: dA (as the logits), softmax backward in registers, dQt = dL Xs (as the aggregation),
+// dXs of the shared nodes on 16x16x4 tiles (contraction over the batch's (agent, head) rows, accumulated over the agent
+// batches), dXs of the hit nodes as 4x4 blocks whose A operand (P and dL of the lane's own hit) never leaves the registers.
+template <int PS, bool HITS, int AB>
+__global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
+  extern __shared__ float4 abd_sm[];
+  using L = AbdLds<PS, HITS>;
+  constexpr int F = 32, NSP = L::NSP, PC = L::PC, PL = L::PL, PTL = L::PTL, NPR = PS + (HITS ? 1 : 0), Wd = F + 4;
+  constexpr int RTS = (NSP + 15) / 16;
+  const Topo& t = a.t;
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x;
+  if (g >= a.G) return;
+  const int n = t.n, S = t.S, Ns = t.Ns, H = a.H, Kp = a.Kp;
+  const int NSH = HITS ? t.n + t.ng : Ns;
+  float* XS = reinterpret_cast<float*>(abd_sm);
+  float* XH = XS + L::XS;
+  float* DZ = XH + L::XH;
+  float* PT = DZ + L::DZ;
+  float* DL = PT + L::PT;
+  const float4* Xa4 = reinterpret_cast<const float4*>(a.Xa + (size_t)g * n * F);
+  const float4* Xo4 = reinterpret_cast<const float4*>(a.Xo + (size_t)g * (Ns - n) * F);
+  const float* qt = a.qt + (size_t)g * n * H * F;
+  const float* dzc = a.dzcat + (size_t)g * n * Kp;
+  const bool want_dx = a.dXa != nullptr;
+  const int il = lane >> 3, sub = lane & 7, g2 = (lane >> 2) & 1, c = lane & 3, hA = lane & 3;
+  const int li = lane & 15, lq = lane >> 4;
+  // ---- every global read is requested before anything waits (clamped addresses, no branches: see the forward) ----
+  float4 vs[PS];
+#pragma unroll
+  for (int p = 0; p < PS; ++p) {
+    const int row = p * 8 + il;
+    const int ra = row < n ? row : n - 1, ro = (row < NSH ? row : NSH - 1) - n;
+    const float4* src = (row < n || NSH == n) ? Xa4 + ra * 8 + sub : Xo4 + ro * 8 + sub;
+    vs[p] = *src;
+  }
+  // the direct x_i part of dzcat for the agent rows of dXa, in the C/D layout of the shared-node tiles
+  float dir[RTS][2][4];
+#pragma unroll
+  for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int node = rt * 16 + lq * 4 + r;
+        dir[rt][ft][r] = dzc[(node < n ? node : n - 1) * Kp + ft * 16 + li];
+      }
+  f32x4g dxs[RTS][2];
+#pragma unroll
+  for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) dxs[rt][ft] = f32x4g{0.f, 0.f, 0.f, 0.f};
+  const float4* ef4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
+  const float* at = a.attn + (size_t)g * n * S * H;
+#pragma unroll
+  for (int ab = 0; ab < AB; ++ab) {       // AB = ceil(n / 8), a compile-time count: straight-line code, every array in registers
+    const int i = ab * 8 + il;
+    const bool live = i < n;
+    const int ic = live ? i : n - 1;
+    float4 vh[HITS ? 8 : 1], vz[5];
+    if constexpr (HITS) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int hb = ab * 64 + k * 8 + il;
+        hb = hb < n * 8 ? hb : n * 8 - 1;
+        vh[k] = Xo4[(t.ng + hb) * 8 + sub];
+      }
+    }
+    // dZ rows of the batch: 32 rows (agent, head) x 9 float4 (32 features + 4 edge terms); rows past n / H duplicate a real
+    // row: they only meet zeros of P and dL
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      int tt = k * 64 + lane;
+      tt = tt < 288 ? tt : 287;
+      const int row = tt / 9, ch = tt - row * 9;
+      int ri = ab * 8 + (row >> 2), rh = row & 3;
+      ri = ri < n ? ri : n - 1; rh = rh < H ? rh : H - 1;
+      vz[k] = *reinterpret_cast<const float4*>(dzc + ri * Kp + F + rh * Wd + ch * 4);
+    }
+    int slot[NPR];
+    float4 efv[NPR];
+    float av[NPR][4];
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) {
+      int sl;
+      if (HITS && p == PS) sl = n + t.gs + sub;
+      else { const int j = p * 8 + sub; sl = (j < NSH) ? slot_of(t, j, ic) : -1; }
+      slot[p] = live ? sl : -1;
+      const int sc = sl < 0 ? 0 : sl;
+      efv[p] = ef4[ic * S + sc];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) av[p][h] = at[(ic * S + sc) * H + (h < H ? h : H - 1)];
+    }
+    // operands that come straight from global memory: the query rows as B operands of the hit-node blocks (feature octet c
+    // of every head of the lane's agent) and of the shared-node tiles (row = agent ks of the batch, head lq)
+    float4 q8[4][2];
+    if constexpr (HITS) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float4* qr = reinterpret_cast<const float4*>(qt + (size_t)(ic * H + (h < H ? h : H - 1)) * F + c * 8);
+        q8[h][0] = qr[0]; q8[h][1] = qr[1];
+      }
+    }
+    float bQ[8][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int ri = ab * 8 + ks;
+      const float* qr = qt + (size_t)((ri < n ? ri : n - 1) * H + (lq < H ? lq : H - 1)) * F;   // rows past n / H: dL is 0 there
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) bQ[ks][ft] = qr[ft * 16 + li];
+    }
+    int pin = 0;
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) {
+      pin |= f4bits(efv[p]);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) pin |= __float_as_int(av[p][h]);
+    }
+    if constexpr (HITS) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) pin |= f4bits(q8[h][0]) | f4bits(q8[h][1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) pin |= __float_as_int(bQ[ks][0]) | __float_as_int(bQ[ks][1]);
+    if (ab == 0) {
+#pragma unroll
+      for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pin |= __float_as_int(dir[rt][ft][r]);
+    }
+    const int pin0 = opaque_zero(pin);
+    if (ab == 0) {
+#pragma unroll
+      for (int p = 0; p < PS; ++p) *reinterpret_cast<float4*>(XS + pin0 + (p * 8 + il) * ABD_XL + sub * 4) = vs[p];
+    }
+    if constexpr (HITS) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(XH + pin0 + (k * 8 + il) * ABD_XL + k * 8 + sub * 4) = vh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int tt = k * 64 + lane, row = tt / 9, ch = tt - row * 9;
+      if (tt < 288) *reinterpret_cast<float4*>(DZ + pin0 + row * ABD_DZL + ch * 4) = vz[k];
+    }
+#pragma unroll
+    for (int p = 0; p < NPR; ++p)
+#pragma unroll
+      for (int h = 0; h < 4; ++h) av[p][h] = (slot[p] >= 0 && h < H) ? av[p][h] : 0.0f;
+    // ---- dA = dZx Xs^T at the lane's slots ----
+    f32x4g acc[NPR];
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) acc[p] = f32x4g{0.f, 0.f, 0.f, 0.f};
+    {
+      const float* zrow = DZ + (il * 4 + hA) * ABD_DZL;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(zrow + k * 4);
+        float4 x[NPR];
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) {
+          if (HITS && p == PS) x[p] = *reinterpret_cast<const float4*>(XH + lane * ABD_XL + il * 8 + k * 4);
+          else x[p] = *reinterpret_cast<const float4*>(XS + (p * 8 + sub) * ABD_XL + k * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int p = 0; p < NPR; ++p) acc[p] = mfma4(f4e(q)[u], f4e(x[p])[u], acc[p]);
+      }
+    }
+    // ---- softmax backward per head: dl = a (dA + dze.e - sum a (dA + dze.e)); tiles: P (shared columns) and dL ----
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float4 dze = *reinterpret_cast<const float4*>(DZ + (il * 4 + h) * ABD_DZL + F);
+      float dot = 0.0f;
+#pragma unroll
+      for (int p = 0; p < NPR; ++p) {
+        const float w = av[p][h];
+        const float4 e = efv[p];
+        // masked slots (a == 0) may carry 5e5 / NaN edge features: never multiply them
+        const float dA = (w != 0.0f) ? acc[p][h] + fmaf(dze.x, e.x, fmaf(dze.y, e.y, fmaf(dze.z, e.z, dze.w * e.w))) : 0.0f;
+        acc[p][h] = dA;
+        dot = fmaf(w, dA, dot);
+      }
+      dot = grp8_sum(dot);
+#pragma unroll
+      for (int p = 0; p < NPR; ++p) {
+        acc[p][h] = av[p][h] * (acc[p][h] - dot);
+        DL[(il * 4 + h) * PL + p * 8 + sub] = acc[p][h];
+        if (p < PS) PT[(il * 4 + h) * PTL + p * 8 + sub] = av[p][h];
+      }
+    }
+    // ---- dQt = dL Xs ----
+    {
+      float pa[PC];
+#pragma unroll
+      for (int k = 0; k < PC / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(DL + (il * 4 + hA) * PL + k * 4);
+        pa[k * 4] = v.x; pa[k * 4 + 1] = v.y; pa[k * 4 + 2] = v.z; pa[k * 4 + 3] = v.w;
+      }
+      f32x4g az[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) az[q] = f32x4g{0.f, 0.f, 0.f, 0.f};
+      const int fq = (g2 * 4 + c) * 4;
+#pragma unroll
+      for (int kk = 0; kk < NSP; ++kk) {
+        const float4 b = *reinterpret_cast<const float4*>(XS + kk * ABD_XL + fq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) az[q] = mfma4(pa[kk], f4e(b)[q], az[q]);
+      }
+      if constexpr (HITS) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float4 b = *reinterpret_cast<const float4*>(XH + (il * 8 + m) * ABD_XL + il * 8 + fq);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) az[q] = mfma4(pa[NSP + m], f4e(b)[q], az[q]);
+        }
+      }
+      if (live) {
+        float* dq = a.dqt + ((size_t)g * n + i) * H * F;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (h < H) *reinterpret_cast<float4*>(dq + h * F + fq) = make_float4(az[0][h], az[1][h], az[2][h], az[3][h]);
+      }
+    }
+    if (want_dx) {
+      // ---- shared nodes: dXs += P^T dZx + dL^T Qt over the 32 (agent, head) rows of the batch ----
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int prow = ks * 4 + lq;                          // = agent ks of the batch, head lq
+        float bD[2];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) bD[ft] = DZ[prow * ABD_DZL + ft * 16 + li];
+#pragma unroll
+        for (int rt = 0; rt < RTS; ++rt) {
+          const int col = (rt * 16 + li < NSP) ? rt * 16 + li : NSP - 1;      // tile rows past NSP are never stored
+          const float aP = PT[prow * PTL + col], aL = DL[prow * PL + col];
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) {
+            dxs[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(aP, bD[ft], dxs[rt][ft], 0, 0, 0);
+            dxs[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL, bQ[ks][ft], dxs[rt][ft], 0, 0, 0);
+          }
+        }
+      }
+      // ---- hit nodes: block (il, g2) = 4 hits x 4 feature octets, k = (head, P | dL) ----
+      if constexpr (HITS) {
+        if (a.dXo != nullptr) {
+          f32x4g af[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) af[q] = f32x4g{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const float4 d0 = *reinterpret_cast<const float4*>(DZ + (il * 4 + h) * ABD_DZL + c * 8);
+            const float4 d1 = *reinterpret_cast<const float4*>(DZ + (il * 4 + h) * ABD_DZL + c * 8 + 4);
+            const float pw = av[PS][h], dw = acc[PS][h];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              af[q] = mfma4(pw, f4e(d0)[q], af[q]);
+              af[q + 4] = mfma4(pw, f4e(d1)[q], af[q + 4]);
+              af[q] = mfma4(dw, f4e(q8[h][0])[q], af[q]);
+              af[q + 4] = mfma4(dw, f4e(q8[h][1])[q], af[q + 4]);
+            }
+          }
+          float4 x0[4], x1[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float* xr = XH + (il * 8 + g2 * 4 + m) * ABD_XL + il * 8 + c * 8;
+            x0[m] = *reinterpret_cast<const float4*>(xr);
+            x1[m] = *reinterpret_cast<const float4*>(xr + 4);
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int hb = ab * 64 + il * 8 + g2 * 4 + m;
+            if (hb < n * 8) {
+              float4 v0 = make_float4(af[0][m], af[1][m], af[2][m], af[3][m]);
+              float4 v1 = make_float4(af[4][m], af[5][m], af[6][m], af[7][m]);
+              if (a.relu_xo) {
+                v0.x = x0[m].x > 0.f ? v0.x : 0.f; v0.y = x0[m].y > 0.f ? v0.y : 0.f; v0.z = x0[m].z > 0.f ? v0.z : 0.f; v0.w = x0[m].w > 0.f ? v0.w : 0.f;
+                v1.x = x1[m].x > 0.f ? v1.x : 0.f; v1.y = x1[m].y > 0.f ? v1.y : 0.f; v1.z = x1[m].z > 0.f ? v1.z : 0.f; v1.w = x1[m].w > 0.f ? v1.w : 0.f;
+              }
+              float* o = a.dXo + ((size_t)g * (Ns - n) + t.ng + hb) * F + c * 8;
+              *reinterpret_cast<float4*>(o) = v0;
+              *reinterpret_cast<float4*>(o + 4) = v1;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (want_dx) {
+    float xm[RTS][2][4];
+#pragma unroll
+    for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int node = rt * 16 + lq * 4 + r;
+          xm[rt][ft][r] = (node < NSP) ? XS[node * ABD_XL + ft * 16 + li] : 0.0f;
+        }
+#pragma unroll
+    for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int node = rt * 16 + lq * 4 + r, f = ft * 16 + li;
+          float v = dxs[rt][ft][r];
+          if (node < n) a.dXa[((size_t)g * n + node) * F + f] = v + dir[rt][ft][r];
+          else if (node < NSH && a.dXo != nullptr) {
+            if (a.relu_xo) v = (xm[rt][ft][r] > 0.0f) ? v : 0.0f;
+            a.dXo[((size_t)g * (Ns - n) + (node - n)) * F + f] = v;
+          }
+        }
+  }
+}
+
+// the block-diagonal kernels apply when the private nodes are exactly 8 LiDAR hits per agent (or there are none)
+static bool attn_bd_shape(const Topo& t, int F, int H, int& PS, bool& hits) {
+  if (F != 32 || H < 1 || H > 4 || getenv("DGPPO_ATTN_NO_BD")) return false;
+  const int n_priv = t.Ns - t.n - t.ng;
+  hits = t.lidar && n_priv > 0;
+  if (hits && (t.per != 8 || n_priv != t.n * 8)) return false;
+  const int nsh = hits ? t.n + t.ng : t.Ns;
+  PS = (nsh + 7) / 8;
+  return PS >= 1 && PS <= 4;
+}
+template <int PS, bool HITS, int AB>
+static void launch_attn_bd_one(const AttnArgs& a, hipStream_t s, bool bwd) {
+  using L = AbdLds<PS, HITS>;
+  if (bwd) hipLaunchKernelGGL((attn_bwd_bd_kernel<PS, HITS, AB>), dim3(a.G), dim3(64), sizeof(float) * L::BWD, s, a);
+  else hipLaunchKernelGGL((attn_fwd_bd_kernel<PS, HITS, AB>), dim3((a.G + 1) / 2), dim3(128), sizeof(float) * 2 * L::FWD, s, a);
+}
+static bool launch_attn_bd(const AttnArgs& a, hipStream_t s, bool bwd) {
+  int PS = 0;
+  bool hits = false;
+  if (!attn_bd_shape(a.t, a.F, a.H, PS, hits)) return false;
+  const int AB = (a.t.n + 7) / 8;                   // agent batches; the shared nodes include the agents, so AB <= (PS + 1) / 2 <= 2
+  switch ((PS * 2 + (hits ? 1 : 0)) * 4 + AB) {
+#define DGPPO_BD(P, HT, B) case ((P) * 2 + (HT)) * 4 + (B): launch_attn_bd_one<P, (HT) != 0, B>(a, s, bwd); return true;
+    DGPPO_BD(1, 0, 1) DGPPO_BD(1, 1, 1) DGPPO_BD(2, 0, 1) DGPPO_BD(2, 1, 1)
+    DGPPO_BD(3, 0, 1) DGPPO_BD(3, 1, 1) DGPPO_BD(3, 0, 2) DGPPO_BD(3, 1, 2)
+    DGPPO_BD(4, 0, 1) DGPPO_BD(4, 1, 1) DGPPO_BD(4, 0, 2) DGPPO_BD(4, 1, 2)
+#undef DGPPO_BD
+    default: return false;
+  }
+}
+
 // dispatch over the compile-time tile counts; returns false if the shape has no instantiation
 template <int F, int CT, int NP>
 static bool launch_attn_wave_sj(const AttnArgs& a, int SJ, int grid, hipStream_t s, bool bwd) {
@@ -1573,6 +2158,7 @@ extern "C" int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
     // multiples of 4 take the workgroup-per-graph kernels below
     // narrow first layer: slot-sparse VALU kernel (one memory round trip per graph); DGPPO_ATTN_DENSE8 forces the MFMA form
     if (F == 8 && !getenv("DGPPO_ATTN_DENSE8")) launched = launch_attn_slot8(a, grid, (hipStream_t)stream, false);
+    if (!launched && F == 32) launched = launch_attn_bd(a, (hipStream_t)stream, false);
     if (launched) {}
     else if (F == 8) launched = launch_attn_wave<8>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, (d.nH + 7) / 8, (t.S + 7) / 8, grid, (hipStream_t)stream);
@@ -1611,6 +2197,7 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
     const int grid = (G + 3) / 4, NP = (d.nH + 7) / 8, SJ = (t.S + 7) / 8;
     a.relu_xo = (relu_xo && dXo) ? 1 : 0;          // fused into the wave kernel's dXo store
     if (F == 8 && !dXa && !getenv("DGPPO_ATTN_DENSE8")) launched = launch_attn_slot8(a, grid, (hipStream_t)stream, true);
+    if (!launched && F == 32) launched = launch_attn_bd(a, (hipStream_t)stream, true);
     if (launched) {}
     else if (F == 8) launched = launch_attn_wave<8>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);
     else if (F == 32) launched = launch_attn_wave<32>(a, d.CT, NP, SJ, grid, (hipStream_t)stream, true);

@@ -598,7 +598,8 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
         return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo, dq_only=dq3)
 
     families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "valu": {"DGPPO_ATTN_VALU": "1"},
-                "dense8": {"DGPPO_ATTN_DENSE8": "1"}}      # F = 8: the matrix-core wave kernels instead of the slot-sparse ones
+                "dense8": {"DGPPO_ATTN_DENSE8": "1"},      # F = 8: the matrix-core wave kernels instead of the slot-sparse ones
+                "wave": {"DGPPO_ATTN_NO_BD": "1"}}         # F = 32: the dense one-wave-per-graph tiles instead of the block-diagonal form
     outs = {}
     for name, env in families.items():
         for k, v in env.items():
@@ -610,7 +611,7 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
     for k, v in ref.items():
         assert torch.isfinite(v).all(), f"default path left non-finite values in {k}"
     _close(ref["dq_only"], ref["dq"], 2e-5, "dqt-only backward vs full backward")
-    for name in ("block", "valu", "dense8"):
+    for name in ("block", "valu", "dense8", "wave"):
         for k in ref:
             _close(outs[name][k], ref[k], 2e-5, f"{name}.{k}")
 
