@@ -201,6 +201,178 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))
   }
 }
 
+// ---- the same chain, rows per WAVE (round 3) ----------------------------------------------------------------------------
+// mlp_gi_fwd_kernel above splits the 64 columns of a 32-row tile over the 4 waves of a workgroup: every LayerNorm needs an
+// exchange through LDS and two workgroup barriers, four barriers per tile at 2 workgroups per CU (232 VGPRs) — its matrix cores
+// are busy 37 % of the time and a launch over 32 768 rows (a rollout step) takes 24 us for 8 us of MFMA work.  Here a WAVE owns
+// 16 rows through the whole chain and all 64 / 192 output columns of every layer:
+//   * the three weight matrices (80 KB) sit in LDS once per CU ([k][c] rows, stride = 1 (mod 64) x 16 so that the B fragment of
+//     a k-step — lane (li, lq) reads W[lq * 16 + kk][ct * 16 + li] — touches 64 different banks); one workgroup of 16 waves
+//     per CU shares them (gfx950: a workgroup may declare all 160 KB);
+//   * LayerNorm statistics are sums over the lane's 4 column tiles + one 16-lane DPP reduction: no exchange, NO barrier after
+//     the weights are staged;
+//   * a layer's output (C/D layout) becomes the next layer's A operand through a wave-private 16 x 68 LDS tile (DS operations of
+//     a wave execute in order); the contraction index is permuted so that a lane's 16 k-values are 16 consecutive columns
+//     (four 16-byte reads; the input rows come straight from global memory the same way).
+#define RW_WL 65
+#define RW_WIL 193
+#define RW_YL 68
+#define RW_WAVES 16
+__global__ void __launch_bounds__(64 * RW_WAVES) mlp_gi_fwd_rw_kernel(MlpGiArgs a) {
+  extern __shared__ float sm[];
+  float* sW1 = sm;                               // [64][65]
+  float* sW2 = sW1 + 64 * RW_WL;                 // [64][65]
+  float* sWi = sW2 + 64 * RW_WL;                 // [64][193]
+  float* sP = sWi + 64 * RW_WIL;                 // b1 g1 be1 b2 g2 be2 (6 x 64), bi (192)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  float* sY = sP + 576 + w * (16 * RW_YL);       // wave-private transposition tile
+  {   // the 80 KB of weights: five 16-byte loads per thread, ALL requested before the first LDS write (a load -> store loop
+      // is one trip to L2 per iteration)
+    static_assert(RW_WAVES == 16, "the staging below assumes 1024 threads");
+    const float4 v1 = reinterpret_cast<const float4*>(a.W1)[tid], v2 = reinterpret_cast<const float4*>(a.W2)[tid];
+    float4 vi[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) vi[j] = reinterpret_cast<const float4*>(a.Wi)[j * 1024 + tid];
+    {
+      const int k = tid >> 4, c = (tid & 15) * 4;
+      float* d1 = sW1 + k * RW_WL + c; float* d2 = sW2 + k * RW_WL + c;
+      d1[0] = v1.x; d1[1] = v1.y; d1[2] = v1.z; d1[3] = v1.w;
+      d2[0] = v2.x; d2[1] = v2.y; d2[2] = v2.z; d2[3] = v2.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = j * 1024 + tid, k = q / 48, c = (q - k * 48) * 4;
+      float* d = sWi + k * RW_WIL + c;
+      d[0] = vi[j].x; d[1] = vi[j].y; d[2] = vi[j].z; d[3] = vi[j].w;
+    }
+  }
+  if (tid < 64) {
+    sP[tid] = a.b1[tid]; sP[64 + tid] = a.g1[tid]; sP[128 + tid] = a.be1[tid];
+    sP[192 + tid] = a.b2[tid]; sP[256 + tid] = a.g2[tid]; sP[320 + tid] = a.be2[tid];
+  }
+  if (tid < 192) sP[384 + tid] = a.bi[tid];
+  __syncthreads();
+  const int n_tiles = (a.M + 15) >> 4;
+  const bool save = a.p1 != nullptr;
+  float A[16];
+  auto fetch = [&](int tile) {                   // A operand of layer 1: row li of the tile, columns lq * 16 .. + 15
+    int row = tile * 16 + li;
+    row = row < a.M ? row : a.M - 1;
+    const float4* p = reinterpret_cast<const float4*>(a.X + (size_t)row * a.ldx + lq * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float4 v = p[j]; A[4 * j] = v.x; A[4 * j + 1] = v.y; A[4 * j + 2] = v.z; A[4 * j + 3] = v.w; }
+  };
+  // one 64-wide layer: acc = A W + b, LayerNorm + ReLU; result to the wave's LDS tile and back as the next A operand
+  auto layer = [&](const float* sW, const float* par, float* p_out, float* y_out, float* st_out, int row0) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B fragments come from LDS: the reads of the NEXT four k-steps are in flight while the matrix cores work on the current
+    // four (left to itself the compiler emits read -> wait -> 2 MFMAs with one pair of registers: the wave idles on every wait)
+    float bw[2][4][4];
+    auto ldw = [&](int buf, int g) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* wr = sW + (lq * 16 + g * 4 + kk) * RW_WL + li;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) bw[buf][kk][ct] = wr[ct * 16];
+      }
+    };
+    ldw(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g + 1 < 4) ldw((g + 1) & 1, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g * 4 + kk], bw[g & 1][kk][ct], acc[ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float b = par[ct * 16 + li];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[ct][r] += b;
+        s[r] += acc[ct][r];
+        q[r] = fmaf(acc[ct][r], acc[ct][r], q[r]);
+        const int row = row0 + lq * 4 + r;
+        if (save && row < a.M) p_out[(size_t)row * FZ_H + ct * 16 + li] = acc[ct][r];
+      }
+    }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mean[r] = row16_sum(s[r]) * (1.0f / 64.0f);
+      const float m2 = row16_sum(q[r]) * (1.0f / 64.0f);
+      rstd[r] = rsqrtf(fmaxf(m2 - mean[r] * mean[r], 0.0f) + 1e-6f);
+      const int row = row0 + lq * 4 + r;
+      if (save && li == 0 && row < a.M) { st_out[(size_t)row * 2] = mean[r]; st_out[(size_t)row * 2 + 1] = rstd[r]; }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const float g = par[64 + ct * 16 + li], e = par[128 + ct * 16 + li];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float y = fmaxf((acc[ct][r] - mean[r]) * rstd[r] * g + e, 0.0f);
+        sY[(lq * 4 + r) * RW_YL + ct * 16 + li] = y;
+        const int row = row0 + lq * 4 + r;
+        if (save && row < a.M) y_out[(size_t)row * FZ_H + ct * 16 + li] = y;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(sY + li * RW_YL + lq * 16 + 4 * j);
+      A[4 * j] = v.x; A[4 * j + 1] = v.y; A[4 * j + 2] = v.z; A[4 * j + 3] = v.w;
+    }
+  };
+  for (int tile = w * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * RW_WAVES) {   // consecutive tiles on different CUs
+    const int row0 = tile * 16;
+    fetch(tile);
+    layer(sW1, sP, a.p1, a.y1, a.st1, row0);
+    layer(sW2, sP + 192, a.p2, a.y2, a.st2, row0);
+    // gate projection: 12 column tiles in two halves (24 accumulator registers at a time)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 ag[6];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) ag[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float bg[2][2][6];                           // two k-steps per group, double-buffered (see layer())
+      auto ldg = [&](int buf, int g) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const float* wr = sWi + (lq * 16 + g * 2 + kk) * RW_WIL + half * 96 + li;
+#pragma unroll
+          for (int t = 0; t < 6; ++t) bg[buf][kk][t] = wr[t * 16];
+        }
+      };
+      ldg(0, 0);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) ldg((g + 1) & 1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int t = 0; t < 6; ++t) ag[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g * 2 + kk], bg[g & 1][kk][t], ag[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int col = half * 96 + t * 16 + li;
+        const float b = sP[384 + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + lq * 4 + r;
+          if (row < a.M) a.gi[(size_t)row * 192 + col] = ag[t][r] + b;
+        }
+      }
+    }
+  }
+}
+
 // ---- backward of the chain above: the three input gradients and the two LayerNorm+ReLU backward passes in ONE launch -----
 //   dy2 = dgi Wi^T,  dpre2 = LNReLU'(p2, y2, st2, g2; dy2),  dy1 = dpre2 W2^T,  dpre1 = LNReLU'(p1, y1, st1, g1; dy1),
 //   dx = dpre1 W1^T  (optionally masked by relu'(mask): the chain's input is a ReLU output for the per-agent networks)
@@ -466,6 +638,28 @@ extern "C" int32_t dgppo_mlp_gi_fwd(const float* X, int32_t ldx, const float* W1
   DGPPO_REQUIRE(!save || (p1 && y1 && st1 && p2 && y2 && st2), "mlp_gi_fwd: the saved activations are all-or-none");
   if (M == 0) return 0;
   MlpGiArgs a{X, ldx, M, W1, b1, g1, be1, W2, b2, g2, be2, Wi, bi, p1, y1, st1, p2, y2, st2, gi};
+  // rows per wave, weights in LDS (one 16-wave workgroup per CU): needs 16-byte addressable input rows
+  if ((ldx & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(W2) |
+                          reinterpret_cast<uintptr_t>(Wi)) & 15) == 0 && !getenv("DGPPO_MLP_GI_TILED")) {
+    static thread_local int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    }
+    const size_t smem_rw = sizeof(float) * (2 * 64 * RW_WL + 64 * RW_WIL + 576 + RW_WAVES * 16 * RW_YL);
+    static thread_local bool attr = false;
+    if (!attr) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gi_fwd_rw_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_rw);
+      DGPPO_REQUIRE(e == hipSuccess, "mlp_gi_fwd: cannot reserve %zu bytes of LDS per workgroup: %s", smem_rw, hipGetErrorString(e));
+      attr = true;
+    }
+    const int tiles16 = (M + 15) / 16;            // spread over every CU even when there are fewer tiles than wave slots
+    hipLaunchKernelGGL(mlp_gi_fwd_rw_kernel, dim3(tiles16 < cus ? tiles16 : cus), dim3(64 * RW_WAVES), smem_rw, (hipStream_t)stream, a);
+    DGPPO_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = sizeof(float) * (3 * FZ_RB * FZ_HL + FZ_RB * 8);
   static thread_local int cap = 0;
   if (cap == 0) {
