@@ -219,6 +219,9 @@ struct AttnArgs {
   float* dXo;            // [G*(Ns-n), F] or NULL
   int relu_xo;           // dXo *= (Xo > 0): Xo is the ReLU output of the previous layer's update (gnn.py:109-111, aggr = 0)
   int G;
+  // block-diagonal kernels only (dgppo_attn_fwd_xo / _bwd_xo): the other nodes' rows are not read but recomputed,
+  // Xo = relu(Xo_raw Wo + bo) with Xo_raw [G*(Ns-n), 8] the padded raw node features (gnn.py:109-111 with aggr = 0)
+  const float* Xo_raw; const float* Wo; const float* bo; int ldwo;
 };
 
 __global__ void __launch_bounds__(256) attn_fwd_valu_kernel(AttnArgs a) {
@@ -1401,7 +1404,97 @@ template <int PS, bool HITS> struct AbdLds {
   static constexpr int BWD = XS + XH + DZ + PT + DL;
 };
 
-template <int PS, bool HITS, int AB>
+// ---- other nodes recomputed in the kernel (XOF variants) ----
+// Goals, LiDAR hits and obstacles receive no messages, so their layer-1 features are relu(x W_u[:8] + b_u) of the 8 raw
+// features (gnn.py:109-111 with aggr = 0).  Materialised, those rows are 9 KB of the 19 KB a graph's forward moves (and are
+// written once and read again by the backward); here the wave reads the 32-byte raw rows and forms the 16-row x 32 tiles on
+// the matrix cores (2 k-steps x 2 column tiles of 16x16x4 per 16 rows) straight into the LDS images.
+#define ABD_KR 8
+template <int GT> struct AbdXoRegs { float ag[GT][2], ah[4][2], wo[2][2], bo[2]; };
+// request the A fragments: row li of each 16-row tile, raw feature lq + 4 s
+template <int GT, bool HITS>
+__device__ inline void abd_xo_load(AbdXoRegs<GT>& x, const AttnArgs& a, const float* raw, int n_shared_other, int ng, int hit0,
+                                   int n_hits, int li, int lq, bool first) {
+  if (first) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) x.wo[s_][ct] = a.Wo[(lq + 4 * s_) * a.ldwo + ct * 16 + li];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) x.bo[ct] = a.bo[ct * 16 + li];
+#pragma unroll
+    for (int t = 0; t < GT; ++t) {
+      int o = t * 16 + li;
+      o = o < n_shared_other ? o : n_shared_other - 1;
+      o = o < 0 ? 0 : o;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) x.ag[t][s_] = raw[o * ABD_KR + lq + 4 * s_];
+    }
+  }
+  if constexpr (HITS) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int hb = hit0 + t * 16 + li;
+      hb = hb < n_hits ? hb : n_hits - 1;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) x.ah[t][s_] = raw[(ng + hb) * ABD_KR + lq + 4 * s_];
+    }
+  }
+}
+// tiles -> LDS images (C/D layout: row lq * 4 + r, column ct * 16 + li)
+template <int GT, bool HITS>
+__device__ inline void abd_xo_emit(const AbdXoRegs<GT>& x, float* XS, float* XH, int n, int n_shared_other, int li, int lq, bool first) {
+  auto tile = [&](const float (&ar)[2], f32x4g (&v)[2]) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      v[ct] = f32x4g{0.f, 0.f, 0.f, 0.f};
+      v[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], x.wo[0][ct], v[ct], 0, 0, 0);
+      v[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[1], x.wo[1][ct], v[ct], 0, 0, 0);
+    }
+  };
+  if (first) {
+#pragma unroll
+    for (int t = 0; t < GT; ++t) {
+      f32x4g v[2];
+      tile(x.ag[t], v);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = t * 16 + lq * 4 + r;
+          if (o < n_shared_other) XS[(n + o) * ABD_XL + ct * 16 + li] = fmaxf(v[ct][r] + x.bo[ct], 0.0f);
+        }
+    }
+  }
+  if constexpr (HITS) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4g v[2];
+      tile(x.ah[t], v);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hr = t * 16 + lq * 4 + r;
+          XH[hr * ABD_XL + (hr >> 3) * 8 + ct * 16 + li] = fmaxf(v[ct][r] + x.bo[ct], 0.0f);
+        }
+    }
+  }
+}
+template <int GT> __device__ inline int abd_xo_bits(const AbdXoRegs<GT>& x, bool hits) {
+  int b = 0;
+#pragma unroll
+  for (int t = 0; t < GT; ++t) b |= __float_as_int(x.ag[t][0]) | __float_as_int(x.ag[t][1]);
+  if (hits) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b |= __float_as_int(x.ah[t][0]) | __float_as_int(x.ah[t][1]);
+  }
+  b |= __float_as_int(x.wo[0][0]) | __float_as_int(x.wo[0][1]) | __float_as_int(x.wo[1][0]) | __float_as_int(x.wo[1][1]);
+  b |= __float_as_int(x.bo[0]) | __float_as_int(x.bo[1]);
+  return b;
+}
+
+template <int PS, bool HITS, int AB, bool XOF>
 __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
   extern __shared__ float4 abd_sm[];
   using L = AbdLds<PS, HITS>;
@@ -1429,9 +1522,13 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
   for (int p = 0; p < PS; ++p) {
     const int row = p * 8 + il;
     const int ra = row < n ? row : n - 1, ro = (row < NSH ? row : NSH - 1) - n;
-    const float4* src = (row < n || NSH == n) ? Xa4 + ra * 8 + sub : Xo4 + ro * 8 + sub;
+    const float4* src = (XOF || row < n || NSH == n) ? Xa4 + ra * 8 + sub : Xo4 + ro * 8 + sub;
     vs[p] = *src;
   }
+  constexpr int GT = (NSP + 15) / 16;
+  AbdXoRegs<GT> xo;
+  const float* raw = XOF ? a.Xo_raw + (size_t)g * (Ns - n) * ABD_KR : nullptr;
+  const int li_ = lane & 15, lq_ = lane >> 4;
   const float* mk = a.emask + (size_t)g * n * S;
   const float4* ef4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
   float* at = a.attn + (size_t)g * n * S * H;
@@ -1441,7 +1538,8 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
     const bool live = i < n;
     const int ic = live ? i : n - 1;
     float4 vh[HITS ? 8 : 1], vq[4];
-    if constexpr (HITS) {
+    if constexpr (XOF) abd_xo_load<GT, HITS>(xo, a, raw, NSH - n, t.ng, ab * 64, n * 8, li_, lq_, ab == 0);
+    if constexpr (HITS && !XOF) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         int hb = ab * 64 + k * 8 + il;
@@ -1473,12 +1571,18 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
     int pin = 0;
 #pragma unroll
     for (int p = 0; p < NPR; ++p) pin |= __float_as_int(mkv[p]) | f4bits(efv[p]);
+    if constexpr (XOF) pin |= abd_xo_bits<GT>(xo, HITS);
     const int pin0 = opaque_zero(pin);
     if (ab == 0) {
 #pragma unroll
-      for (int p = 0; p < PS; ++p) *reinterpret_cast<float4*>(XS + pin0 + (p * 8 + il) * ABD_XL + sub * 4) = vs[p];
+      for (int p = 0; p < PS; ++p) {
+        float4 v = vs[p];
+        if (XOF && p * 8 + il >= n) v = make_float4(0.f, 0.f, 0.f, 0.f);       // pad rows stay zero, the others are recomputed below
+        *reinterpret_cast<float4*>(XS + pin0 + (p * 8 + il) * ABD_XL + sub * 4) = v;
+      }
     }
-    if constexpr (HITS) {
+    if constexpr (XOF) abd_xo_emit<GT, HITS>(xo, XS + pin0, XH + pin0, n, NSH - n, li_, lq_, ab == 0);
+    if constexpr (HITS && !XOF) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(XH + pin0 + (k * 8 + il) * ABD_XL + k * 8 + sub * 4) = vh[k];
     }
@@ -1593,7 +1697,7 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
 // backward of the block-diagonal form: dA (as the logits), softmax backward in registers, dQt = dL Xs (as the aggregation),
 // dXs of the shared nodes on 16x16x4 tiles (contraction over the batch's (agent, head) rows, accumulated over the agent
 // batches), dXs of the hit nodes as 4x4 blocks whose A operand (P and dL of the lane's own hit) never leaves the registers.
-template <int PS, bool HITS, int AB>
+template <int PS, bool HITS, int AB, bool XOF>
 __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
   extern __shared__ float4 abd_sm[];
   using L = AbdLds<PS, HITS>;
@@ -1623,9 +1727,13 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
   for (int p = 0; p < PS; ++p) {
     const int row = p * 8 + il;
     const int ra = row < n ? row : n - 1, ro = (row < NSH ? row : NSH - 1) - n;
-    const float4* src = (row < n || NSH == n) ? Xa4 + ra * 8 + sub : Xo4 + ro * 8 + sub;
+    const float4* src = (XOF || row < n || NSH == n) ? Xa4 + ra * 8 + sub : Xo4 + ro * 8 + sub;
     vs[p] = *src;
   }
+  constexpr int GT = (NSP + 15) / 16;
+  AbdXoRegs<GT> xo;
+  const float* raw = XOF ? a.Xo_raw + (size_t)g * (Ns - n) * ABD_KR : nullptr;
+  const int li_ = lane & 15, lq_ = lane >> 4;
   // the direct x_i part of dzcat for the agent rows of dXa, in the C/D layout of the shared-node tiles
   float dir[RTS][2][4];
 #pragma unroll
@@ -1650,7 +1758,8 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
     const bool live = i < n;
     const int ic = live ? i : n - 1;
     float4 vh[HITS ? 8 : 1], vz[5];
-    if constexpr (HITS) {
+    if constexpr (XOF) abd_xo_load<GT, HITS>(xo, a, raw, NSH - n, t.ng, ab * 64, n * 8, li_, lq_, ab == 0);
+    if constexpr (HITS && !XOF) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         int hb = ab * 64 + k * 8 + il;
@@ -1722,12 +1831,18 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) pin |= __float_as_int(dir[rt][ft][r]);
     }
+    if constexpr (XOF) pin |= abd_xo_bits<GT>(xo, HITS);
     const int pin0 = opaque_zero(pin);
     if (ab == 0) {
 #pragma unroll
-      for (int p = 0; p < PS; ++p) *reinterpret_cast<float4*>(XS + pin0 + (p * 8 + il) * ABD_XL + sub * 4) = vs[p];
+      for (int p = 0; p < PS; ++p) {
+        float4 v = vs[p];
+        if (XOF && p * 8 + il >= n) v = make_float4(0.f, 0.f, 0.f, 0.f);       // pad rows stay zero, the others are recomputed below
+        *reinterpret_cast<float4*>(XS + pin0 + (p * 8 + il) * ABD_XL + sub * 4) = v;
+      }
     }
-    if constexpr (HITS) {
+    if constexpr (XOF) abd_xo_emit<GT, HITS>(xo, XS + pin0, XH + pin0, n, NSH - n, li_, lq_, ab == 0);
+    if constexpr (HITS && !XOF) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(XH + pin0 + (k * 8 + il) * ABD_XL + k * 8 + sub * 4) = vh[k];
     }
@@ -1918,11 +2033,16 @@ static bool attn_bd_shape(const Topo& t, int F, int H, int& PS, bool& hits) {
   PS = (nsh + 7) / 8;
   return PS >= 1 && PS <= 4;
 }
+template <int PS, bool HITS, int AB, bool XOF>
+static void launch_attn_bd_x(const AttnArgs& a, hipStream_t s, bool bwd) {
+  using L = AbdLds<PS, HITS>;
+  if (bwd) hipLaunchKernelGGL((attn_bwd_bd_kernel<PS, HITS, AB, XOF>), dim3(a.G), dim3(64), sizeof(float) * L::BWD, s, a);
+  else hipLaunchKernelGGL((attn_fwd_bd_kernel<PS, HITS, AB, XOF>), dim3((a.G + 1) / 2), dim3(128), sizeof(float) * 2 * L::FWD, s, a);
+}
 template <int PS, bool HITS, int AB>
 static void launch_attn_bd_one(const AttnArgs& a, hipStream_t s, bool bwd) {
-  using L = AbdLds<PS, HITS>;
-  if (bwd) hipLaunchKernelGGL((attn_bwd_bd_kernel<PS, HITS, AB>), dim3(a.G), dim3(64), sizeof(float) * L::BWD, s, a);
-  else hipLaunchKernelGGL((attn_fwd_bd_kernel<PS, HITS, AB>), dim3((a.G + 1) / 2), dim3(128), sizeof(float) * 2 * L::FWD, s, a);
+  if (a.Xo_raw != nullptr) launch_attn_bd_x<PS, HITS, AB, true>(a, s, bwd);
+  else launch_attn_bd_x<PS, HITS, AB, false>(a, s, bwd);
 }
 static bool launch_attn_bd(const AttnArgs& a, hipStream_t s, bool bwd) {
   int PS = 0;
@@ -2213,6 +2333,61 @@ extern "C" int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H
       return dgppo_relu_bwd(dXo, Xo, (int64_t)G * (t.Ns - t.n) * F, stream);
     return 0;
   }
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- the same layer with the other nodes' rows recomputed inside the kernel (block-diagonal kernels only) ------------------
+// Xo = relu(Xo_raw Wo + bo), Xo_raw [G*(Ns-n), 8] = the padded raw features of goals / hits / obstacles, Wo [8, ldwo >= 32] =
+// the first 8 rows of the previous layer's update weight, bo [32] its bias: what the reference computes for nodes without
+// incoming edges (gnn.py:109-111 with aggr = 0) and then feeds to the next GraphTransformer layer as sender rows
+// (gnn.py:85-117).  dgppo_attn_xo_supported tells the caller whether the topology has such a kernel; if not, materialise Xo
+// (dgppo_dense_fwd) and call dgppo_attn_fwd / dgppo_attn_bwd.
+static bool attn_xo_ok(const Topo& t, int F, int H, int Kp) {
+  int PS = 0;
+  bool hits = false;
+  return t.Ns > t.n && (Kp & 3) == 0 && t.S <= 64 && t.n * H * H < 65536 && !getenv("DGPPO_ATTN_VALU") && !getenv("DGPPO_ATTN_BLOCK") &&
+         !getenv("DGPPO_ATTN_NO_XO") && attn_bd_shape(t, F, H, PS, hits);
+}
+extern "C" int32_t dgppo_attn_xo_supported(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp) {
+  AttnArgs a{};
+  if (attn_check(cfg, F, H, Kp, 0, a)) return 0;
+  return attn_xo_ok(a.t, F, H, Kp) ? 1 : 0;
+}
+extern "C" int32_t dgppo_attn_fwd_xo(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* qt, const float* Xa,
+                                     const float* Xo_raw, const float* Wo, int32_t ldwo, const float* bo, const float* efeat,
+                                     const float* emask, float* zcat, float* attn, int32_t G, void* stream) {
+  AttnArgs a{};
+  int32_t rc = attn_check(cfg, F, H, Kp, G, a);
+  if (rc) return rc;
+  if (G == 0) return 0;
+  DGPPO_REQUIRE(qt && Xa && Xo_raw && Wo && bo && efeat && emask && zcat, "attn_fwd_xo: NULL operand");
+  DGPPO_REQUIRE(ldwo >= 32, "attn_fwd_xo: ldwo=%d < 32", ldwo);
+  DGPPO_REQUIRE(attn_xo_ok(a.t, F, H, Kp), "attn_fwd_xo: no fused kernel for this topology (ask dgppo_attn_xo_supported)");
+  a.qt = qt; a.Xa = Xa; a.Xo = nullptr; a.efeat = efeat; a.emask = emask; a.zcat = zcat; a.attn = attn;
+  a.Xo_raw = Xo_raw; a.Wo = Wo; a.ldwo = ldwo; a.bo = bo;
+  const bool launched = launch_attn_bd(a, (hipStream_t)stream, false);
+  DGPPO_REQUIRE(launched, "attn_fwd_xo: dispatch failed");
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t dgppo_attn_bwd_xo(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
+                                     const float* attn, const float* qt, const float* Xa, const float* Xo_raw, const float* Wo,
+                                     int32_t ldwo, const float* bo, const float* efeat, float* dqt, float* dXa, float* dXo,
+                                     int32_t relu_xo, int32_t G, void* stream) {
+  AttnArgs a{};
+  int32_t rc = attn_check(cfg, F, H, Kp, G, a);
+  if (rc) return rc;
+  if (G == 0) return 0;
+  DGPPO_REQUIRE(dzcat && attn && qt && Xa && Xo_raw && Wo && bo && efeat && dqt, "attn_bwd_xo: NULL operand");
+  DGPPO_REQUIRE(ldwo >= 32, "attn_bwd_xo: ldwo=%d < 32", ldwo);
+  DGPPO_REQUIRE(!(dXo && !dXa), "attn_bwd_xo: dXo needs dXa");
+  DGPPO_REQUIRE(attn_xo_ok(a.t, F, H, Kp), "attn_bwd_xo: no fused kernel for this topology (ask dgppo_attn_xo_supported)");
+  a.dzcat = dzcat; a.attn = (float*)attn; a.qt = qt; a.Xa = Xa; a.Xo = nullptr; a.efeat = efeat; a.dqt = dqt; a.dXa = dXa; a.dXo = dXo;
+  a.relu_xo = (relu_xo && dXo) ? 1 : 0;
+  a.Xo_raw = Xo_raw; a.Wo = Wo; a.ldwo = ldwo; a.bo = bo;
+  const bool launched = launch_attn_bd(a, (hipStream_t)stream, true);
+  DGPPO_REQUIRE(launched, "attn_bwd_xo: dispatch failed");
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

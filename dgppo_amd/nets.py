@@ -195,6 +195,19 @@ class Net:
             K.gnn_prep(q("Wq"), q("bq"), q("Wk"), q("Wv"), q("bv"), q("We"), q("Wu"), self.pp(f"gnn{l}.Mcat"),
                        self.pp(f"gnn{l}.cvec"), self.pp(f"gnn{l}.Wout"), f, fp, d, H_HEADS, kp)
 
+    def _xo_fusable(self, l: int) -> bool:
+        """may layer l + 1's attention recompute the other nodes' rows relu(Xo_l Wout_l[:fp] + bu_l) itself?  Only from the
+        8-wide raw features (l = 0) into a LAST layer (a third layer would need the rows as a tensor), and only where the C ABI
+        has such a kernel for the topology (dgppo_attn_xo_supported)."""
+        if l != 0 or self.gnn_layers != 2:
+            return False
+        key = "_xo_ok"
+        if not hasattr(self, key):
+            f1, fp1, d1, kp1 = self.dims[1]
+            setattr(self, key, self.dims[0][1] == 8 and self.dims[0][2] == 32 and fp1 == 32 and
+                    K.attn_xo_supported(self.cfg, fp1, H_HEADS, kp1))
+        return getattr(self, key)
+
     def zero_grads(self):
         # (the prepared-weight gradients are zero between backward passes: backward() clears them after mapping them back)
         self.grads.zero_()
@@ -210,20 +223,32 @@ class Net:
         Ro = G * feats.n_other
         act = {"feats": feats, "G": G, "n_seq": n_seq, "T": T}
         Xa, Xo = feats.Xa, feats.Xo
+        xo_fused = None
         for l, (f, fp, d, kp) in enumerate(self.dims):
             qt = A.get(f"{tag}.qt{l}", R, H_HEADS * fp)
             K.dense_fwd(Xa, self.pp(f"gnn{l}.Mcat"), self.pp(f"gnn{l}.cvec"), qt)
             zcat = A.get(f"{tag}.zcat{l}", R, kp)
             attn = A.get(f"{tag}.attn{l}", R, cfg.fan_in, H_HEADS) if train else None    # only the backward reads the weights
-            K.attn_fwd(cfg, fp, H_HEADS, kp, qt, Xa, Xo if Ro > 0 else None, feats.efeat, feats.emask, zcat, attn, G)
+            if xo_fused is not None:      # other nodes' rows recomputed in the kernel from the raw features (see below)
+                K.attn_fwd_xo(cfg, fp, H_HEADS, kp, qt, Xa, xo_fused[0], xo_fused[1], xo_fused[2], feats.efeat, feats.emask, zcat, attn, G)
+            else:
+                K.attn_fwd(cfg, fp, H_HEADS, kp, qt, Xa, Xo if Ro > 0 else None, feats.efeat, feats.emask, zcat, attn, G)
+            act[f"xo_fused{l}"] = xo_fused
+            xo_fused = None
             Xa_n = A.get(f"{tag}.Xa{l + 1}", R, d)
             K.dense_fwd(zcat, self.pp(f"gnn{l}.Wout"), self.p(f"gnn{l}.bu"), Xa_n, act=1)
             act[f"Xa{l}"], act[f"Xo{l}"], act[f"qt{l}"], act[f"zcat{l}"], act[f"attn{l}"] = Xa, Xo, qt, zcat, attn
             if l < self.gnn_layers - 1 and Ro > 0:
-                Xo_n = A.get(f"{tag}.Xo{l + 1}", Ro, d)
                 # goals / hits / obstacles receive no messages: relu(W_u x + b_u)  (gnn.py:109-111 with aggr = 0)
-                K.dense_fwd(Xo, self.pp(f"gnn{l}.Wout")[:fp], self.p(f"gnn{l}.bu"), Xo_n, act=1)
-                Xo = Xo_n
+                if self._xo_fusable(l):
+                    # ... and when the next layer is the last one, its attention kernels recompute these rows from the 8 raw
+                    # features instead of reading 32-wide rows that are written here and read twice more (forward, backward)
+                    xo_fused = (Xo, self.pp(f"gnn{l}.Wout")[:fp], self.p(f"gnn{l}.bu"))
+                    Xo = None
+                else:
+                    Xo_n = A.get(f"{tag}.Xo{l + 1}", Ro, d)
+                    K.dense_fwd(Xo, self.pp(f"gnn{l}.Wout")[:fp], self.p(f"gnn{l}.bu"), Xo_n, act=1)
+                    Xo = Xo_n
             Xa = Xa_n
         act[f"Xa{self.gnn_layers}"] = Xa
         if self.kind == "Vl":  # RStateFn: mean over agents (value.py:33)
@@ -494,9 +519,14 @@ class Net:
             dXo_prev = dXo
             dXo_l = A.get(f"{tag}.dXo{l}", Ro, fp) if (need_dx and Ro > 0) else None
             more_dXo = dXo_prev is not None and dXo_l is not None       # a dense term still accumulates into dXo_l (>= 3 layers)
-            K.attn_bwd(cfg, fp, H_HEADS, kp, dz, act[f"attn{l}"], act[f"qt{l}"], act[f"Xa{l}"],
-                       act[f"Xo{l}"] if Ro > 0 else None, feats.efeat, dqt, dXa_l, dXo_l, G,
-                       relu_xo=(dXo_l is not None and not more_dXo))
+            xf = act.get(f"xo_fused{l}")
+            if xf is not None:
+                K.attn_bwd_xo(cfg, fp, H_HEADS, kp, dz, act[f"attn{l}"], act[f"qt{l}"], act[f"Xa{l}"], xf[0], xf[1], xf[2],
+                              feats.efeat, dqt, dXa_l, dXo_l, G, relu_xo=(dXo_l is not None and not more_dXo))
+            else:
+                K.attn_bwd(cfg, fp, H_HEADS, kp, dz, act[f"attn{l}"], act[f"qt{l}"], act[f"Xa{l}"],
+                           act[f"Xo{l}"] if Ro > 0 else None, feats.efeat, dqt, dXa_l, dXo_l, G,
+                           relu_xo=(dXo_l is not None and not more_dXo))
             K.dense_bwd_w(act[f"Xa{l}"], dqt, self.pg(f"gnn{l}.Mcat"), self.pg(f"gnn{l}.cvec"))
             if need_dx:
                 K.dense_fwd(dqt, self.pp(f"gnn{l}.Mcat"), None, dXa_l, accumulate=True, trans_w=True, relu_mask=act[f"Xa{l}"])

@@ -281,6 +281,53 @@ def attn_bwd(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo, efeat, dqt, dXa, dXo, G, re
     N.check(rc, "dgppo_attn_bwd")
 
 
+def attn_xo_supported(cfg, F, H, Kp) -> bool:
+    """does the topology have an attention kernel that recomputes the other nodes' rows (dgppo_attn_fwd_xo / _bwd_xo)?"""
+    return bool(N.lib().dgppo_attn_xo_supported(C.byref(cfg), F, H, Kp))
+
+
+def _wo_ptr(Wo):
+    if not Wo.is_cuda or Wo.dtype != torch.float32:
+        raise TypeError("Wo must be a float32 GPU tensor")
+    return C.c_void_p(Wo.data_ptr())
+
+
+def _wo_ld(Wo):
+    if Wo.dim() != 2 or Wo.shape[0] != 8 or Wo.shape[1] < 32 or Wo.stride(1) != 1:
+        raise ValueError(f"Wo must be [8, >= 32] with contiguous rows, got {tuple(Wo.shape)} strides {Wo.stride()}")
+    return int(Wo.stride(0))
+
+
+def attn_fwd_xo(cfg, F, H, Kp, qt, Xa, Xo_raw, Wo, bo, efeat, emask, zcat, attn, G):
+    """attn_fwd with Xo = relu(Xo_raw Wo + bo) recomputed in the kernel (Xo_raw [G*n_other, 8], Wo [8, 32] rows of a wider matrix)."""
+    n, S = cfg.n_agents, cfg.fan_in
+    N.expect_shape(qt, (G * n, H * F), "qt")
+    N.expect_shape(Xa, (G * n, F), "Xa")
+    N.expect_shape(zcat, (G * n, Kp), "zcat")
+    N.expect_shape(Xo_raw, (G * (cfg.num_nodes - 1 - n), 8), "Xo_raw")
+    N.expect_shape(bo, (32,), "bo")
+    if attn is not None:
+        N.expect_shape(attn, (G * n, S, H), "attn")
+    FLOPS[0] += 2.0 * G * n * H * S * (2 * F + 4) + 2.0 * G * (cfg.num_nodes - 1 - n) * 8 * 32
+    rc = N.lib().dgppo_attn_fwd_xo(C.byref(cfg), F, H, Kp, _p(qt), _p(Xa), _p(Xo_raw), _wo_ptr(Wo),
+                                   _wo_ld(Wo), _p(bo), _p(efeat), _p(emask), _p(zcat), _p(attn), G, N.stream_ptr())
+    N.check(rc, "dgppo_attn_fwd_xo")
+
+
+def attn_bwd_xo(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo_raw, Wo, bo, efeat, dqt, dXa, dXo, G, relu_xo: bool = False):
+    n = cfg.n_agents
+    N.expect_shape(dzcat, (G * n, Kp), "dzcat")
+    N.expect_shape(dqt, (G * n, H * F), "dqt")
+    N.expect_shape(Xo_raw, (G * (cfg.num_nodes - 1 - n), 8), "Xo_raw")
+    if dXa is not None:
+        N.expect_shape(dXa, (G * n, F), "dXa")
+    FLOPS[0] += 4.0 * G * n * H * cfg.fan_in * (2 * F + 4) + 2.0 * G * (cfg.num_nodes - 1 - n) * 8 * 32
+    rc = N.lib().dgppo_attn_bwd_xo(C.byref(cfg), F, H, Kp, _p(dzcat), _p(attn), _p(qt), _p(Xa), _p(Xo_raw),
+                                   _wo_ptr(Wo), _wo_ld(Wo), _p(bo), _p(efeat), _p(dqt), _p(dXa), _p(dXo),
+                                   int(relu_xo), G, N.stream_ptr())
+    N.check(rc, "dgppo_attn_bwd_xo")
+
+
 def gnn_prep(Wq, bq, Wk, Wv, bv, We, Wu, Mcat, cvec, Wout, F, Fp, D, H, Kp):
     rc = N.lib().dgppo_gnn_prep(_p(Wq), _p(bq), _p(Wk), _p(Wv), _p(bv), _p(We), _p(Wu), _p(Mcat), _p(cvec), _p(Wout),
                                 F, Fp, D, H, Kp, N.stream_ptr())

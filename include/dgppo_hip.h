@@ -265,6 +265,23 @@ int32_t dgppo_attn_fwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t K
 int32_t dgppo_attn_bwd(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
                        const float* attn, const float* qt, const float* Xa, const float* Xo, const float* efeat,
                        float* dqt, float* dXa, float* dXo, int32_t relu_xo, int32_t G, void* stream);
+/* The same layer (F = 32) with the sender rows of the nodes WITHOUT incoming edges (goals, LiDAR hits, obstacles) recomputed
+ * inside the kernel instead of read: Xo = relu(Xo_raw Wo + bo), Xo_raw [G*(Ns-n),8] their padded raw features, Wo [8,ldwo] the
+ * first 8 rows of the previous layer's update weight (Wout of dgppo_gnn_prep), bo [32] its bias — what the reference's
+ * GraphTransformer layer produces for a node with aggr = 0 (dgppo/nn/gnn.py:109-111) before the next layer reads it as a
+ * sender (gnn.py:85-117).  Saves the 9 KB per graph of materialised rows in the forward and again in the backward.
+ * dgppo_attn_xo_supported: 1 if the topology has such a kernel (8 LiDAR hits per agent or no private nodes, <= 32 shared
+ * nodes, H <= 4), else 0 -> materialise Xo with dgppo_dense_fwd and call dgppo_attn_fwd / dgppo_attn_bwd.
+ * dXo of the backward is the gradient w.r.t. the RECOMPUTED rows (relu_xo != 0: already multiplied by relu'), i.e. exactly
+ * what dgppo_dense_bwd_w needs for dWo / dbo.                                                                            */
+int32_t dgppo_attn_xo_supported(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp);
+int32_t dgppo_attn_fwd_xo(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* qt, const float* Xa,
+                          const float* Xo_raw, const float* Wo, int32_t ldwo, const float* bo, const float* efeat,
+                          const float* emask, float* zcat, float* attn, int32_t G, void* stream);
+int32_t dgppo_attn_bwd_xo(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
+                          const float* attn, const float* qt, const float* Xa, const float* Xo_raw, const float* Wo,
+                          int32_t ldwo, const float* bo, const float* efeat, float* dqt, float* dXa, float* dXo,
+                          int32_t relu_xo, int32_t G, void* stream);
 
 /* GraphTransformer parameters (flax Dense_0..4 = q,k,v,e,u; gnn.py:86-110) -> Mcat [Fp,H*Fp], cvec [H*Fp],
  * Wout [Kp,D] used by dgppo_attn_* and the surrounding Denses; and the adjoint map (accumulates into d*).           */

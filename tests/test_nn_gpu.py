@@ -663,6 +663,58 @@ def test_attention_wave_kernels_across_topologies(cuda, monkeypatch, kind, n, n_
             _close(got[k], ref[k], 2e-5, f"F={F} {k}")
 
 
+@pytest.mark.parametrize("kind,n,n_obs", [(0, 8, 3), (0, 3, 0), (0, 10, 3), (1, 6, 2), (3, 4, 3), (2, 16, 8)])
+def test_attention_with_recomputed_other_nodes(cuda, kind, n, n_obs):
+    """dgppo_attn_fwd_xo / _bwd_xo recompute the sender rows of the nodes without incoming edges, relu(Xo_raw Wo + bo), inside
+    the kernel (gnn.py:109-111 with aggr = 0 feeding gnn.py:85-117); they must agree with materialising those rows (torch) and
+    calling dgppo_attn_fwd / _bwd, forward and backward, with and without the ReLU mask on dXo."""
+    from dgppo_amd import _native as N, ops_nn as K_
+    cfg = N.make_env_cfg(kind, n, n_obs)
+    F, Kp, H, S = 32, 144, 3, cfg.fan_in
+    n_other = cfg.num_nodes - 1 - n
+    if not K_.attn_xo_supported(cfg, F, H, Kp):
+        pytest.skip("no fused kernel for this topology")
+    G = 19
+    gen = torch.Generator().manual_seed(kind * 100 + n * 10 + n_obs + 7)
+    R = G * n
+    qt = torch.randn(R, H * F, generator=gen).to(cuda)
+    Xa = torch.randn(R, F, generator=gen).to(cuda)
+    raw = torch.randn(G * n_other, 8, generator=gen).to(cuda)
+    Wfull = (torch.randn(Kp, 32, generator=gen) * 0.5).to(cuda)         # the rows [:8] of a wider matrix, as in the network
+    Wo, bo = Wfull[:8], (torch.randn(32, generator=gen) * 0.3).to(cuda)
+    Xo = torch.relu(raw @ Wo + bo).contiguous()
+    em = (torch.rand(R, S, generator=gen) > 0.3).float()
+    em[:, 0] = 1.0
+    ef = torch.randn(R, S, 4, generator=gen)
+    ef[em == 0] = float("nan")
+    em, ef = em.to(cuda), ef.to(cuda)
+    dz = torch.randn(R, Kp, generator=gen).to(cuda)
+
+    def run(fused, relu_xo):
+        z = torch.full((R, Kp), float("nan"), device=cuda)
+        at = torch.full((R, S, H), float("nan"), device=cuda)
+        dq = torch.full((R, H * F), float("nan"), device=cuda)
+        dXa = torch.full((R, F), float("nan"), device=cuda)
+        dXo = torch.full((G * n_other, F), float("nan"), device=cuda)
+        if fused:
+            K_.attn_fwd_xo(cfg, F, H, Kp, qt, Xa, raw, Wo, bo, ef, em, z, at, G)
+            K_.attn_bwd_xo(cfg, F, H, Kp, dz, at, qt, Xa, raw, Wo, bo, ef, dq, dXa, dXo, G, relu_xo=relu_xo)
+            z2 = torch.full((R, Kp), float("nan"), device=cuda)
+            K_.attn_fwd_xo(cfg, F, H, Kp, qt, Xa, raw, Wo, bo, ef, em, z2, None, G)       # inference form: no weights kept
+            assert torch.equal(z2, z)
+        else:
+            K_.attn_fwd(cfg, F, H, Kp, qt, Xa, Xo, ef, em, z, at, G)
+            K_.attn_bwd(cfg, F, H, Kp, dz, at, qt, Xa, Xo, ef, dq, dXa, dXo, G, relu_xo=relu_xo)
+        torch.cuda.synchronize()
+        return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo)
+
+    for relu_xo in (False, True):
+        got, ref = run(True, relu_xo), run(False, relu_xo)
+        for k in ref:
+            assert torch.isfinite(got[k]).all(), f"{k} not finite"
+            _close(got[k], ref[k], 2e-5, f"relu_xo={relu_xo} {k}")
+
+
 @pytest.mark.parametrize("M,K,N,acc", [(1000, 96, 32, True), (513, 64, 64, False), (70, 24, 8, True)])
 def test_dense_fwd_relu_mask_epilogue(cuda, M, K, N, acc):
     """dgppo_dense_fwd(relu_mask=...): Y = where(mask > 0, X W^T (+ Y), 0) — the ReLU backward fused into the kernel that
