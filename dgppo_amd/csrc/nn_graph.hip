@@ -222,6 +222,9 @@ struct AttnArgs {
   // block-diagonal kernels only (dgppo_attn_fwd_xo / _bwd_xo): the other nodes' rows are not read but recomputed,
   // Xo = relu(Xo_raw Wo + bo) with Xo_raw [G*(Ns-n), 8] the padded raw node features (gnn.py:109-111 with aggr = 0)
   const float* Xo_raw; const float* Wo; const float* bo; int ldwo;
+  // backward with recomputed rows: instead of writing dXo, every graph writes raw^T dXo [8 x 32] and colsum dXo [32] (the gradient
+  // of Wo / bo through the ReLU) to dwo_slab + g * ABD_DW_STRIDE; a reduce kernel adds the slabs up
+  float* dwo_slab;
 };
 
 __global__ void __launch_bounds__(256) attn_fwd_valu_kernel(AttnArgs a) {
@@ -1410,6 +1413,7 @@ template <int PS, bool HITS> struct AbdLds {
 // written once and read again by the backward); here the wave reads the 32-byte raw rows and forms the 16-row x 32 tiles on
 // the matrix cores (2 k-steps x 2 column tiles of 16x16x4 per 16 rows) straight into the LDS images.
 #define ABD_KR 8
+#define ABD_DW_STRIDE 320              // 8 x 32 (dWo) + 32 (dbo), rounded to 64 floats
 template <int GT> struct AbdXoRegs { float ag[GT][2], ah[4][2], wo[2][2], bo[2]; };
 // request the A fragments: row li of each 16-row tile, raw feature lq + 4 s
 template <int GT, bool HITS>
@@ -1750,6 +1754,7 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
   for (int rt = 0; rt < RTS; ++rt)
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) dxs[rt][ft] = f32x4g{0.f, 0.f, 0.f, 0.f};
+  f32x4g dwacc[2] = {f32x4g{0.f, 0.f, 0.f, 0.f}, f32x4g{0.f, 0.f, 0.f, 0.f}};      // XOF + dwo_slab: (dWo | dbo)^T, rows f, columns k
   const float4* ef4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
   const float* at = a.attn + (size_t)g * n * S * H;
 #pragma unroll
@@ -1952,7 +1957,7 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
       }
       // ---- hit nodes: block (il, g2) = 4 hits x 4 feature octets, k = (head, P | dL) ----
       if constexpr (HITS) {
-        if (a.dXo != nullptr) {
+        if (a.dXo != nullptr || (XOF && a.dwo_slab != nullptr)) {
           f32x4g af[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) af[q] = f32x4g{0.f, 0.f, 0.f, 0.f};
@@ -1976,19 +1981,42 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
             x0[m] = *reinterpret_cast<const float4*>(xr);
             x1[m] = *reinterpret_cast<const float4*>(xr + 4);
           }
+          const bool to_slab = XOF && a.dwo_slab != nullptr;
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const int hb = ab * 64 + il * 8 + g2 * 4 + m;
-            if (hb < n * 8) {
-              float4 v0 = make_float4(af[0][m], af[1][m], af[2][m], af[3][m]);
-              float4 v1 = make_float4(af[4][m], af[5][m], af[6][m], af[7][m]);
-              if (a.relu_xo) {
-                v0.x = x0[m].x > 0.f ? v0.x : 0.f; v0.y = x0[m].y > 0.f ? v0.y : 0.f; v0.z = x0[m].z > 0.f ? v0.z : 0.f; v0.w = x0[m].w > 0.f ? v0.w : 0.f;
-                v1.x = x1[m].x > 0.f ? v1.x : 0.f; v1.y = x1[m].y > 0.f ? v1.y : 0.f; v1.z = x1[m].z > 0.f ? v1.z : 0.f; v1.w = x1[m].w > 0.f ? v1.w : 0.f;
-              }
+            float4 v0 = make_float4(af[0][m], af[1][m], af[2][m], af[3][m]);
+            float4 v1 = make_float4(af[4][m], af[5][m], af[6][m], af[7][m]);
+            if (a.relu_xo || to_slab) {
+              v0.x = x0[m].x > 0.f ? v0.x : 0.f; v0.y = x0[m].y > 0.f ? v0.y : 0.f; v0.z = x0[m].z > 0.f ? v0.z : 0.f; v0.w = x0[m].w > 0.f ? v0.w : 0.f;
+              v1.x = x1[m].x > 0.f ? v1.x : 0.f; v1.y = x1[m].y > 0.f ? v1.y : 0.f; v1.z = x1[m].z > 0.f ? v1.z : 0.f; v1.w = x1[m].w > 0.f ? v1.w : 0.f;
+            }
+            if (to_slab) {            // the hit image becomes the image of its gradient (rows of agents past n: zeros, P and dL are 0 there)
+              float* xr = XH + (il * 8 + g2 * 4 + m) * ABD_XL + il * 8 + c * 8;
+              *reinterpret_cast<float4*>(xr) = v0;
+              *reinterpret_cast<float4*>(xr + 4) = v1;
+            } else if (hb < n * 8) {
               float* o = a.dXo + ((size_t)g * (Ns - n) + t.ng + hb) * F + c * 8;
               *reinterpret_cast<float4*>(o) = v0;
               *reinterpret_cast<float4*>(o + 4) = v1;
+            }
+          }
+          if constexpr (XOF) {
+            if (to_slab) {
+              // dWo^T [f][k] += sum over the batch's 64 hit rows dX[row][f] raw[row][k]  (column 8 of B = 1: the bias gradient)
+#pragma unroll
+              for (int s_ = 0; s_ < 16; ++s_) {
+                const int hr = s_ * 4 + lq;
+                int hb = ab * 64 + hr;
+                hb = hb < n * 8 ? hb : n * 8 - 1;
+                const float rv = raw[(t.ng + hb) * ABD_KR + (li < 8 ? li : 0)];
+                const float bv = li < 8 ? rv : (li == 8 ? 1.0f : 0.0f);
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                  const float av_ = XH[hr * ABD_XL + (hr >> 3) * 8 + ft * 16 + li];
+                  dwacc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv, dwacc[ft], 0, 0, 0);
+                }
+              }
             }
           }
         }
@@ -2015,11 +2043,37 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
           const int node = rt * 16 + lq * 4 + r, f = ft * 16 + li;
           float v = dxs[rt][ft][r];
           if (node < n) a.dXa[((size_t)g * n + node) * F + f] = v + dir[rt][ft][r];
-          else if (node < NSH && a.dXo != nullptr) {
+          else if (XOF && a.dwo_slab != nullptr) {
+            if (node < NSP) XS[node * ABD_XL + f] = (node < NSH && xm[rt][ft][r] > 0.0f) ? v : 0.0f;   // gradient image of the shared other rows
+          } else if (node < NSH && a.dXo != nullptr) {
             if (a.relu_xo) v = (xm[rt][ft][r] > 0.0f) ? v : 0.0f;
             a.dXo[((size_t)g * (Ns - n) + (node - n)) * F + f] = v;
           }
         }
+    if constexpr (XOF) {
+      if (a.dwo_slab != nullptr) {
+        const int nsho = NSH - n;
+#pragma unroll
+        for (int s_ = 0; s_ < NSP / 4; ++s_) {
+          const int o = s_ * 4 + lq;
+          const int oc = o < nsho ? o : nsho - 1;
+          const float rv = raw[oc * ABD_KR + (li < 8 ? li : 0)];
+          const float bv = li < 8 ? rv : (li == 8 ? 1.0f : 0.0f);
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft) {
+            const int node = n + o;
+            const float av_ = (o < nsho && node < NSP) ? XS[(node < NSP ? node : NSP - 1) * ABD_XL + ft * 16 + li] : 0.0f;
+            dwacc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv, dwacc[ft], 0, 0, 0);
+          }
+        }
+        if (li <= 8) {
+          float* o = a.dwo_slab + (size_t)g * ABD_DW_STRIDE + li * 32 + lq * 4;
+#pragma unroll
+          for (int ft = 0; ft < 2; ++ft)
+            *reinterpret_cast<float4*>(o + ft * 16) = make_float4(dwacc[ft][0], dwacc[ft][1], dwacc[ft][2], dwacc[ft][3]);
+        }
+      }
+    }
   }
 }
 
@@ -2388,6 +2442,55 @@ extern "C" int32_t dgppo_attn_bwd_xo(const dgppo_env_cfg* cfg, int32_t F, int32_
   a.Xo_raw = Xo_raw; a.Wo = Wo; a.ldwo = ldwo; a.bo = bo;
   const bool launched = launch_attn_bd(a, (hipStream_t)stream, true);
   DGPPO_REQUIRE(launched, "attn_bwd_xo: dispatch failed");
+  DGPPO_LAUNCH_CHECK();
+  return 0;
+}
+
+// sum of the per-graph slabs of attn_bwd_bd_kernel<.., XOF>: dWo [8, lddwo] += , dbo [32] +=
+__global__ void __launch_bounds__(320) attn_xo_dw_reduce_kernel(const float* slab, int G, float* dWo, int lddwo, float* dbo) {
+  const int e = threadIdx.x;                      // 0..287: k * 32 + f, then the 32 bias entries
+  if (e >= 288) return;
+  const int per = (G + gridDim.x - 1) / gridDim.x;
+  const int g0 = blockIdx.x * per, g1 = min(G, g0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = g0;
+  for (; g + 3 < g1; g += 4) {
+    s0 += slab[(size_t)g * ABD_DW_STRIDE + e]; s1 += slab[(size_t)(g + 1) * ABD_DW_STRIDE + e];
+    s2 += slab[(size_t)(g + 2) * ABD_DW_STRIDE + e]; s3 += slab[(size_t)(g + 3) * ABD_DW_STRIDE + e];
+  }
+  for (; g < g1; ++g) s0 += slab[(size_t)g * ABD_DW_STRIDE + e];
+  const float sum = (s0 + s1) + (s2 + s3);
+  if (g0 >= g1) return;
+  if (e < 256) atomicAdd(dWo + (size_t)(e >> 5) * lddwo + (e & 31), sum);
+  else atomicAdd(dbo + (e - 256), sum);
+}
+extern "C" int64_t dgppo_attn_xo_workspace_bytes(int32_t G) { return G < 0 ? 0 : (int64_t)G * ABD_DW_STRIDE * (int64_t)sizeof(float); }
+// dgppo_attn_bwd_xo that CONSUMES the gradient of the recomputed rows instead of writing it: dWo [8, lddwo] += Xo_raw^T dpre,
+// dbo [32] += colsum dpre with dpre = relu'(Xo) * dXo — the weight gradient jax.grad assigns to the previous layer's update Dense
+// for the nodes without incoming edges (gnn.py:109-111).  workspace: dgppo_attn_xo_workspace_bytes(G) bytes, caller-owned.
+extern "C" int32_t dgppo_attn_bwd_xo_dw(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
+                                        const float* attn, const float* qt, const float* Xa, const float* Xo_raw, const float* Wo,
+                                        int32_t ldwo, const float* bo, const float* efeat, float* dqt, float* dXa, float* dWo,
+                                        int32_t lddwo, float* dbo, float* workspace, int64_t workspace_bytes, int32_t G,
+                                        void* stream) {
+  AttnArgs a{};
+  int32_t rc = attn_check(cfg, F, H, Kp, G, a);
+  if (rc) return rc;
+  if (G == 0) return 0;
+  DGPPO_REQUIRE(dzcat && attn && qt && Xa && Xo_raw && Wo && bo && efeat && dqt && dXa && dWo && dbo && workspace,
+                "attn_bwd_xo_dw: NULL operand");
+  DGPPO_REQUIRE(ldwo >= 32 && lddwo >= 32, "attn_bwd_xo_dw: ldwo=%d lddwo=%d < 32", ldwo, lddwo);
+  DGPPO_REQUIRE(workspace_bytes >= dgppo_attn_xo_workspace_bytes(G) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                "attn_bwd_xo_dw: workspace too small or not 16-byte aligned");
+  DGPPO_REQUIRE(attn_xo_ok(a.t, F, H, Kp), "attn_bwd_xo_dw: no fused kernel for this topology (ask dgppo_attn_xo_supported)");
+  a.dzcat = dzcat; a.attn = (float*)attn; a.qt = qt; a.Xa = Xa; a.Xo = nullptr; a.efeat = efeat; a.dqt = dqt; a.dXa = dXa; a.dXo = nullptr;
+  a.relu_xo = 1;
+  a.Xo_raw = Xo_raw; a.Wo = Wo; a.ldwo = ldwo; a.bo = bo; a.dwo_slab = workspace;
+  const bool launched = launch_attn_bd(a, (hipStream_t)stream, true);
+  DGPPO_REQUIRE(launched, "attn_bwd_xo_dw: dispatch failed");
+  int blocks = (G + 127) / 128;
+  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+  hipLaunchKernelGGL(attn_xo_dw_reduce_kernel, dim3(blocks), dim3(320), 0, (hipStream_t)stream, workspace, G, dWo, lddwo, dbo);
   DGPPO_LAUNCH_CHECK();
   return 0;
 }

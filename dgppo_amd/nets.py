@@ -520,7 +520,13 @@ class Net:
             dXo_l = A.get(f"{tag}.dXo{l}", Ro, fp) if (need_dx and Ro > 0) else None
             more_dXo = dXo_prev is not None and dXo_l is not None       # a dense term still accumulates into dXo_l (>= 3 layers)
             xf = act.get(f"xo_fused{l}")
-            if xf is not None:
+            if xf is not None and dXa_l is not None and not more_dXo and not os.environ.get("DGPPO_ATTN_XO_NO_DW"):
+                # the gradient of the recomputed rows never leaves the kernel: it goes straight into dWout_{l-1}[:8] / dbu_{l-1}
+                ws = A.get(f"{tag}.xo_ws", K.attn_xo_workspace_floats(G), 1).view(-1)
+                K.attn_bwd_xo_dw(cfg, fp, H_HEADS, kp, dz, act[f"attn{l}"], act[f"qt{l}"], act[f"Xa{l}"], xf[0], xf[1], xf[2],
+                                 feats.efeat, dqt, dXa_l, self.pg(f"gnn{l - 1}.Wout")[:self.dims[l - 1][1]], self.g(f"gnn{l - 1}.bu"), ws, G)
+                dXo_l = None
+            elif xf is not None:
                 K.attn_bwd_xo(cfg, fp, H_HEADS, kp, dz, act[f"attn{l}"], act[f"qt{l}"], act[f"Xa{l}"], xf[0], xf[1], xf[2],
                               feats.efeat, dqt, dXa_l, dXo_l, G, relu_xo=(dXo_l is not None and not more_dXo))
             else:

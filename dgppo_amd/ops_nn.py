@@ -328,6 +328,26 @@ def attn_bwd_xo(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo_raw, Wo, bo, efeat, dqt, 
     N.check(rc, "dgppo_attn_bwd_xo")
 
 
+def attn_xo_workspace_floats(G: int) -> int:
+    return int(N.lib().dgppo_attn_xo_workspace_bytes(int(G))) // 4
+
+
+def attn_bwd_xo_dw(cfg, F, H, Kp, dzcat, attn, qt, Xa, Xo_raw, Wo, bo, efeat, dqt, dXa, dWo, dbo, workspace, G):
+    """attn_bwd_xo that consumes the gradient of the recomputed rows: dWo [8, >= 32 wide rows] += Xo_raw^T (relu' * dXo),
+    dbo [32] += its column sums; workspace: attn_xo_workspace_floats(G) floats."""
+    n = cfg.n_agents
+    N.expect_shape(dzcat, (G * n, Kp), "dzcat")
+    N.expect_shape(dqt, (G * n, H * F), "dqt")
+    N.expect_shape(dXa, (G * n, F), "dXa")
+    N.expect_shape(Xo_raw, (G * (cfg.num_nodes - 1 - n), 8), "Xo_raw")
+    N.expect_shape(dbo, (32,), "dbo")
+    FLOPS[0] += 4.0 * G * n * H * cfg.fan_in * (2 * F + 4) + 4.0 * G * (cfg.num_nodes - 1 - n) * 8 * 32
+    rc = N.lib().dgppo_attn_bwd_xo_dw(C.byref(cfg), F, H, Kp, _p(dzcat), _p(attn), _p(qt), _p(Xa), _p(Xo_raw), _wo_ptr(Wo), _wo_ld(Wo),
+                                      _p(bo), _p(efeat), _p(dqt), _p(dXa), _wo_ptr(dWo), _wo_ld(dWo), _p(dbo), _p(workspace),
+                                      C.c_int64(workspace.numel() * 4), G, N.stream_ptr())
+    N.check(rc, "dgppo_attn_bwd_xo_dw")
+
+
 def gnn_prep(Wq, bq, Wk, Wv, bv, We, Wu, Mcat, cvec, Wout, F, Fp, D, H, Kp):
     rc = N.lib().dgppo_gnn_prep(_p(Wq), _p(bq), _p(Wk), _p(Wv), _p(bv), _p(We), _p(Wu), _p(Mcat), _p(cvec), _p(Wout),
                                 F, Fp, D, H, Kp, N.stream_ptr())

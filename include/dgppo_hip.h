@@ -282,6 +282,16 @@ int32_t dgppo_attn_bwd_xo(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_
                           const float* attn, const float* qt, const float* Xa, const float* Xo_raw, const float* Wo,
                           int32_t ldwo, const float* bo, const float* efeat, float* dqt, float* dXa, float* dXo,
                           int32_t relu_xo, int32_t G, void* stream);
+/* dgppo_attn_bwd_xo that CONSUMES the gradient of the recomputed rows instead of writing it (9 KB per graph that
+ * dgppo_dense_bwd_w would read again): dWo [8,lddwo] += Xo_raw^T dpre, dbo [32] += colsum(dpre), dpre = relu'(Xo) * dXo — the
+ * weight gradient jax.grad gives the previous layer's update Dense for the nodes without incoming edges (gnn.py:109-111).
+ * workspace: dgppo_attn_xo_workspace_bytes(G) bytes, caller-owned, 16-byte aligned (per-graph partial sums, reduced by a
+ * second launch on the same stream).                                                                                      */
+int64_t dgppo_attn_xo_workspace_bytes(int32_t G);
+int32_t dgppo_attn_bwd_xo_dw(const dgppo_env_cfg* cfg, int32_t F, int32_t H, int32_t Kp, const float* dzcat,
+                             const float* attn, const float* qt, const float* Xa, const float* Xo_raw, const float* Wo,
+                             int32_t ldwo, const float* bo, const float* efeat, float* dqt, float* dXa, float* dWo,
+                             int32_t lddwo, float* dbo, float* workspace, int64_t workspace_bytes, int32_t G, void* stream);
 
 /* GraphTransformer parameters (flax Dense_0..4 = q,k,v,e,u; gnn.py:86-110) -> Mcat [Fp,H*Fp], cvec [H*Fp],
  * Wout [Kp,D] used by dgppo_attn_* and the surrounding Denses; and the adjoint map (accumulates into d*).           */

@@ -713,6 +713,24 @@ def test_attention_with_recomputed_other_nodes(cuda, kind, n, n_obs):
         for k in ref:
             assert torch.isfinite(got[k]).all(), f"{k} not finite"
             _close(got[k], ref[k], 2e-5, f"relu_xo={relu_xo} {k}")
+    # the variant that consumes the gradient of the recomputed rows: dWo += raw^T (relu' dXo), dbo += its column sums
+    ref = run(False, True)
+    at = torch.empty(R, S, H, device=cuda)
+    z = torch.empty(R, Kp, device=cuda)
+    K_.attn_fwd_xo(cfg, F, H, Kp, qt, Xa, raw, Wo, bo, ef, em, z, at, G)
+    dq = torch.full((R, H * F), float("nan"), device=cuda)
+    dXa = torch.full((R, F), float("nan"), device=cuda)
+    dWfull = torch.full((Kp, 32), 0.25, device=cuda)              # accumulated into, rows [:8] of a wider gradient
+    dbo = torch.full((32,), -0.5, device=cuda)
+    ws = torch.empty(K_.attn_xo_workspace_floats(G), device=cuda)
+    K_.attn_bwd_xo_dw(cfg, F, H, Kp, dz, at, qt, Xa, raw, Wo, bo, ef, dq, dXa, dWfull[:8], dbo, ws, G)
+    torch.cuda.synchronize()
+    _close(dq, ref["dq"], 2e-5, "dw variant dq")
+    _close(dXa, ref["dXa"], 2e-5, "dw variant dXa")
+    dXo64 = ref["dXo"].double()
+    _close(dWfull[:8], (0.25 + raw.double().t() @ dXo64).float(), 2e-5, "dWo")
+    _close(dbo, (-0.5 + dXo64.sum(0)).float(), 2e-5, "dbo")
+    assert torch.equal(dWfull[8:], torch.full((Kp - 8, 32), 0.25, device=cuda)), "rows past 8 of the wider gradient were touched"
 
 
 @pytest.mark.parametrize("M,K,N,acc", [(1000, 96, 32, True), (513, 64, 64, False), (70, 24, 8, True)])
