@@ -1755,6 +1755,7 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) dxs[rt][ft] = f32x4g{0.f, 0.f, 0.f, 0.f};
   f32x4g dwacc[2] = {f32x4g{0.f, 0.f, 0.f, 0.f}, f32x4g{0.f, 0.f, 0.f, 0.f}};      // XOF + dwo_slab: (dWo | dbo)^T, rows f, columns k
+  float rbg[NSP / 4];
   const float4* ef4 = reinterpret_cast<const float4*>(a.efeat + (size_t)g * n * S * 4);
   const float* at = a.attn + (size_t)g * n * S * H;
 #pragma unroll
@@ -1764,6 +1765,28 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
     const int ic = live ? i : n - 1;
     float4 vh[HITS ? 8 : 1], vz[5];
     if constexpr (XOF) abd_xo_load<GT, HITS>(xo, a, raw, NSH - n, t.ng, ab * 64, n * 8, li_, lq_, ab == 0);
+    // B operands of the weight-gradient contraction (dgppo_attn_bwd_xo_dw): raw feature li & 7 of other-row 4 s + lq, requested
+    // with everything else (read in the loop that uses them they were 16 dependent trips to L2)
+    float rbh[HITS ? 16 : 1];
+    if constexpr (XOF && HITS) {
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) {
+        int hb = ab * 64 + s_ * 4 + lq;
+        hb = hb < n * 8 ? hb : n * 8 - 1;
+        rbh[s_] = raw[(t.ng + hb) * ABD_KR + (li & 7)];
+      }
+    }
+    if constexpr (XOF) {
+      if (ab == 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < NSP / 4; ++s_) {
+          int o = s_ * 4 + lq;
+          o = o < NSH - n ? o : NSH - n - 1;
+          o = o < 0 ? 0 : o;
+          rbg[s_] = raw[o * ABD_KR + (li & 7)];
+        }
+      }
+    }
     if constexpr (HITS && !XOF) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1837,6 +1860,16 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
           for (int r = 0; r < 4; ++r) pin |= __float_as_int(dir[rt][ft][r]);
     }
     if constexpr (XOF) pin |= abd_xo_bits<GT>(xo, HITS);
+    if constexpr (XOF && HITS) {
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) pin |= __float_as_int(rbh[s_]);
+    }
+    if constexpr (XOF) {
+      if (ab == 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < NSP / 4; ++s_) pin |= __float_as_int(rbg[s_]);
+      }
+    }
     const int pin0 = opaque_zero(pin);
     if (ab == 0) {
 #pragma unroll
@@ -2007,10 +2040,7 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
 #pragma unroll
               for (int s_ = 0; s_ < 16; ++s_) {
                 const int hr = s_ * 4 + lq;
-                int hb = ab * 64 + hr;
-                hb = hb < n * 8 ? hb : n * 8 - 1;
-                const float rv = raw[(t.ng + hb) * ABD_KR + (li < 8 ? li : 0)];
-                const float bv = li < 8 ? rv : (li == 8 ? 1.0f : 0.0f);
+                const float bv = li < 8 ? rbh[s_] : (li == 8 ? 1.0f : 0.0f);
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
                   const float av_ = XH[hr * ABD_XL + (hr >> 3) * 8 + ft * 16 + li];
@@ -2056,9 +2086,7 @@ __global__ void __launch_bounds__(64) attn_bwd_bd_kernel(AttnArgs a) {
 #pragma unroll
         for (int s_ = 0; s_ < NSP / 4; ++s_) {
           const int o = s_ * 4 + lq;
-          const int oc = o < nsho ? o : nsho - 1;
-          const float rv = raw[oc * ABD_KR + (li < 8 ? li : 0)];
-          const float bv = li < 8 ? rv : (li == 8 ? 1.0f : 0.0f);
+          const float bv = li < 8 ? rbg[s_] : (li == 8 ? 1.0f : 0.0f);
 #pragma unroll
           for (int ft = 0; ft < 2; ++ft) {
             const int node = n + o;
@@ -2452,14 +2480,14 @@ __global__ void __launch_bounds__(320) attn_xo_dw_reduce_kernel(const float* sla
   if (e >= 288) return;
   const int per = (G + gridDim.x - 1) / gridDim.x;
   const int g0 = blockIdx.x * per, g1 = min(G, g0 + per);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int g = g0;
-  for (; g + 3 < g1; g += 4) {
-    s0 += slab[(size_t)g * ABD_DW_STRIDE + e]; s1 += slab[(size_t)(g + 1) * ABD_DW_STRIDE + e];
-    s2 += slab[(size_t)(g + 2) * ABD_DW_STRIDE + e]; s3 += slab[(size_t)(g + 3) * ABD_DW_STRIDE + e];
+  for (; g + 7 < g1; g += 8) {                     // eight loads in flight per thread
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sacc[u] += slab[(size_t)(g + u) * ABD_DW_STRIDE + e];
   }
-  for (; g < g1; ++g) s0 += slab[(size_t)g * ABD_DW_STRIDE + e];
-  const float sum = (s0 + s1) + (s2 + s3);
+  for (; g < g1; ++g) sacc[0] += slab[(size_t)g * ABD_DW_STRIDE + e];
+  const float sum = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
   if (g0 >= g1) return;
   if (e < 256) atomicAdd(dWo + (size_t)(e >> 5) * lddwo + (e & 31), sum);
   else atomicAdd(dbo + (e - 256), sum);
@@ -2488,8 +2516,8 @@ extern "C" int32_t dgppo_attn_bwd_xo_dw(const dgppo_env_cfg* cfg, int32_t F, int
   a.Xo_raw = Xo_raw; a.Wo = Wo; a.ldwo = ldwo; a.bo = bo; a.dwo_slab = workspace;
   const bool launched = launch_attn_bd(a, (hipStream_t)stream, true);
   DGPPO_REQUIRE(launched, "attn_bwd_xo_dw: dispatch failed");
-  int blocks = (G + 127) / 128;
-  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+  int blocks = (G + 31) / 32;                      // 32 graphs per workgroup: <= 512 atomics per address at 16 384 graphs
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   hipLaunchKernelGGL(attn_xo_dw_reduce_kernel, dim3(blocks), dim3(320), 0, (hipStream_t)stream, workspace, G, dWo, lddwo, dbo);
   DGPPO_LAUNCH_CHECK();
   return 0;

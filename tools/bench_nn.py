@@ -82,6 +82,13 @@ if which in ("all", "attn"):
             timeit(f"attn_bwd G={G} F={F}", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, dXa, dXo, G))
             if F == 32:   # how much of the wide backward is the input gradient (dXs: 160 of its 320 MFMAs, 10 KB of stores per graph)
                 timeit(f"attn_bwd G={G} F={F} (dqt only)", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, None, None, G))
+            if F == 32 and K.attn_xo_supported(cfg, F, 3, Kp):   # other-node rows recomputed from the raw features in the kernel
+                raw = torch.randn(Xo.shape[0], 8, device=dev); Wo = torch.randn(8, 32, device=dev) * 0.5; bo = torch.randn(32, device=dev) * 0.3
+                timeit(f"attn_fwd_xo G={G} F={F}", lambda: K.attn_fwd_xo(cfg, F, 3, Kp, qt, Xa, raw, Wo, bo, ef, em, z, at, G))
+                timeit(f"attn_fwd_xo G={G} F={F} (inference)", lambda: K.attn_fwd_xo(cfg, F, 3, Kp, qt, Xa, raw, Wo, bo, ef, em, z, None, G))
+                timeit(f"attn_bwd_xo G={G} F={F}", lambda: K.attn_bwd_xo(cfg, F, 3, Kp, z, at, qt, Xa, raw, Wo, bo, ef, dq, dXa, dXo, G, relu_xo=True))
+                dWo = torch.zeros(8, 32, device=dev); dbo = torch.zeros(32, device=dev); ws = torch.empty(K.attn_xo_workspace_floats(G), device=dev)
+                timeit(f"attn_bwd_xo_dw G={G} F={F} (+ slab reduce)", lambda: K.attn_bwd_xo_dw(cfg, F, 3, Kp, z, at, qt, Xa, raw, Wo, bo, ef, dq, dXa, dWo, dbo, ws, G))
             if F == 8:    # the first layer needs no input gradient
                 timeit(f"attn_bwd G={G} F={F} (dqt only)", lambda: K.attn_bwd(cfg, F, 3, Kp, z, at, qt, Xa, Xo, ef, dq, None, None, G))
 if which in ("all", "fused"):
