@@ -1518,6 +1518,7 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
   const float4* qt4 = reinterpret_cast<const float4*>(a.qt + (size_t)g * n * H * F);
   float* zc = a.zcat + (size_t)g * n * Kp;
   const int il = lane >> 3, sub = lane & 7, g2 = (lane >> 2) & 1, c = lane & 3, hA = lane & 3;
+  ASTAMP(0);
   // ---- every global read is requested before anything waits: rows are fetched unconditionally from clamped addresses (a
   //      pad row duplicates a real one; it only ever meets zeros of P), so there is no branch around a load and the wave
   //      makes ONE trip to memory per agent batch ----
@@ -1572,6 +1573,7 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
       mkv[p] = mk[ic * S + sc];
       efv[p] = ef4[ic * S + sc];
     }
+    ASTAMP(1);
     int pin = 0;
 #pragma unroll
     for (int p = 0; p < NPR; ++p) pin |= __float_as_int(mkv[p]) | f4bits(efv[p]);
@@ -1594,6 +1596,7 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
     for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(QP + pin0 + (k * 8 + il) * ABD_XL + sub * 4) = vq[k];
 #pragma unroll
     for (int p = 0; p < NPR; ++p) mkv[p] = (slot[p] >= 0) ? mkv[p] : 0.0f;
+    ASTAMP(2);
     // ---- logits: A = the query row of (agent il, head hA), B = the lane's own node rows ----
     f32x4g acc[NPR];
 #pragma unroll
@@ -1615,6 +1618,7 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
           for (int p = 0; p < NPR; ++p) acc[p] = mfma4(f4e(q)[u], f4e(x[p])[u], acc[p]);
       }
     }
+    ASTAMP(3);
     // ---- masked softmax per head over the 8 lanes x NPR registers of the agent; edge aggregation; P -> LDS ----
     float* PT = QP;                                            // DS operations of a wave execute in order: the query rows are read
 #pragma unroll
@@ -1652,6 +1656,7 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
 #pragma unroll
       for (int p = 0; p < NPR; ++p) PT[(il * 4 + h) * PL + p * 8 + sub] = acc[p][h];
     }
+    ASTAMP(4);
     // ---- Zx = P Xs: A = row (il, hA) of P, B = feature quad (g2 * 4 + c) of the node of the k-step ----
     {
       float pa[PC];
@@ -1685,6 +1690,7 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
       }
     }
   }
+  ASTAMP(5);
   // the parts of zcat that are plain copies: x_i (from its staged image), the constant column, zero padding
 #pragma unroll
   for (int p = 0; p < PS; ++p) {
@@ -1695,6 +1701,224 @@ __global__ void __launch_bounds__(128) attn_fwd_bd_kernel(AttnArgs a) {
     const int wpad = Kp - kc;                                  // >= 1: the constant column, then zeros
     for (int i = lane; i < n; i += 64)
       for (int cc = 0; cc < wpad; ++cc) zc[i * Kp + kc + cc] = (cc == 0) ? 1.0f : 0.0f;
+  }
+  ASTAMP(6);
+}
+
+// ---- the same forward with PERSISTENT waves and the next graph's loads in flight (n <= 8: one agent batch) ----------------
+// A third of a wave's time per graph is the wait for its one trip to memory (in-kernel stamps: 6.7 k of 21 k cycles) and LDS
+// limits a CU to 10 of these waves, so that wait is not hidden.  Here a wave walks graphs g, g + W, g + 2 W, ...; the loads of
+// the next graph are requested right after the current one's rows are staged and land during its MFMA / softmax phases (+55
+// registers: 8 instead of 10 waves per CU).  Launches of up to twice the resident waves keep the kernel above (rollouts).
+template <int PS, bool HITS, bool XOF>
+struct AbdFwdRegs {
+  float4 vs[PS], vq[4], vh[(HITS && !XOF) ? 8 : 1];
+  AbdXoRegs<(PS * 8 + 15) / 16> xo;
+  float mkv[PS + (HITS ? 1 : 0)];
+  float4 efv[PS + (HITS ? 1 : 0)];
+};
+template <int PS, bool HITS, bool XOF>
+__global__ void __launch_bounds__(128) attn_fwd_bdp_kernel(AttnArgs a) {
+  extern __shared__ float4 abd_sm[];
+  using L = AbdLds<PS, HITS>;
+  constexpr int F = 32, NSP = L::NSP, PC = L::PC, PL = L::PL, NPR = PS + (HITS ? 1 : 0), Wd = F + 4, GT = (NSP + 15) / 16;
+  const Topo& t = a.t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 2 + wave);
+  const int stride = gridDim.x * 2;
+  if (g >= a.G) return;                                        // no barriers below
+  const int n = t.n, S = t.S, Ns = t.Ns, H = a.H, Kp = a.Kp;
+  const int NSH = HITS ? t.n + t.ng : Ns;
+  const int kc = F + H * Wd;
+  float* XS = reinterpret_cast<float*>(abd_sm) + wave * L::FWD;
+  float* XH = XS + L::XS;
+  float* QP = XH + L::XH;
+  const int il = lane >> 3, sub = lane & 7, g2 = (lane >> 2) & 1, c = lane & 3, hA = lane & 3;
+  const int li_ = lane & 15, lq_ = lane >> 4;
+  const int i = il;
+  const bool live = i < n;
+  const int ic = live ? i : n - 1;
+  // the lane's slots do not depend on the graph
+  int slot[NPR], sc[NPR];
+#pragma unroll
+  for (int p = 0; p < NPR; ++p) {
+    int sl;
+    if (HITS && p == PS) sl = n + t.gs + sub;
+    else { const int j = p * 8 + sub; sl = (j < NSH) ? slot_of(t, j, ic) : -1; }
+    slot[p] = live ? sl : -1;
+    sc[p] = sl < 0 ? 0 : sl;
+  }
+  using Regs = AbdFwdRegs<PS, HITS, XOF>;
+  auto load = [&](int gg, Regs& R) {
+    const float4* Xa4 = reinterpret_cast<const float4*>(a.Xa + (size_t)gg * n * F);
+    const float4* Xo4 = reinterpret_cast<const float4*>(a.Xo + (size_t)gg * (Ns - n) * F);
+    const float4* qt4 = reinterpret_cast<const float4*>(a.qt + (size_t)gg * n * H * F);
+#pragma unroll
+    for (int p = 0; p < PS; ++p) {
+      const int row = p * 8 + il;
+      const int ra = row < n ? row : n - 1, ro = (row < NSH ? row : NSH - 1) - n;
+      const float4* src = (XOF || row < n || NSH == n) ? Xa4 + ra * 8 + sub : Xo4 + ro * 8 + sub;
+      R.vs[p] = *src;
+    }
+    if constexpr (XOF) abd_xo_load<GT, HITS>(R.xo, a, a.Xo_raw + (size_t)gg * (Ns - n) * ABD_KR, NSH - n, t.ng, 0, n * 8, li_, lq_, true);
+    if constexpr (HITS && !XOF) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int hb = k * 8 + il;
+        hb = hb < n * 8 ? hb : n * 8 - 1;
+        R.vh[k] = Xo4[(t.ng + hb) * 8 + sub];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = k * 8 + il;
+      int ri = row >> 2, rh = row & 3;
+      ri = ri < n ? ri : n - 1; rh = rh < H ? rh : H - 1;
+      R.vq[k] = qt4[(ri * H + rh) * 8 + sub];
+    }
+    const float* mk = a.emask + (size_t)gg * n * S;
+    const float4* ef4 = reinterpret_cast<const float4*>(a.efeat + (size_t)gg * n * S * 4);
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) {
+      R.mkv[p] = mk[ic * S + sc[p]];
+      R.efv[p] = ef4[ic * S + sc[p]];
+    }
+  };
+  auto stage = [&](Regs& R) {
+    int pin = 0;
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) pin |= __float_as_int(R.mkv[p]) | f4bits(R.efv[p]);
+    if constexpr (XOF) pin |= abd_xo_bits<GT>(R.xo, HITS);
+    const int pin0 = opaque_zero(pin);
+#pragma unroll
+    for (int p = 0; p < PS; ++p) {
+      float4 v = R.vs[p];
+      if (XOF && p * 8 + il >= n) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(XS + pin0 + (p * 8 + il) * ABD_XL + sub * 4) = v;
+    }
+    if constexpr (XOF) abd_xo_emit<GT, HITS>(R.xo, XS + pin0, XH + pin0, n, NSH - n, li_, lq_, true);
+    if constexpr (HITS && !XOF) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<float4*>(XH + pin0 + (k * 8 + il) * ABD_XL + k * 8 + sub * 4) = R.vh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(QP + pin0 + (k * 8 + il) * ABD_XL + sub * 4) = R.vq[k];
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) R.mkv[p] = (slot[p] >= 0) ? R.mkv[p] : 0.0f;
+  };
+  auto compute = [&](int gg, const Regs& R) {
+    float* zc = a.zcat + (size_t)gg * n * Kp;
+    float* at = a.attn + (size_t)gg * n * S * H;
+    f32x4g acc[NPR];
+#pragma unroll
+    for (int p = 0; p < NPR; ++p) acc[p] = f32x4g{0.f, 0.f, 0.f, 0.f};
+    {
+      const float* qrow = QP + (il * 4 + hA) * ABD_XL;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(qrow + k * 4);
+        float4 x[NPR];
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) {
+          if (HITS && p == PS) x[p] = *reinterpret_cast<const float4*>(XH + lane * ABD_XL + il * 8 + k * 4);
+          else x[p] = *reinterpret_cast<const float4*>(XS + (p * 8 + sub) * ABD_XL + k * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int p = 0; p < NPR; ++p) acc[p] = mfma4(f4e(q)[u], f4e(x[p])[u], acc[p]);
+      }
+    }
+    float* PT = QP;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (h < H) {
+        float l[NPR];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) { l[p] = (R.mkv[p] != 0.0f) ? acc[p][h] : -INFINITY; mx = fmaxf(mx, l[p]); }
+        mx = grp8_max(mx);
+        float den = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) { l[p] = (l[p] == -INFINITY) ? 0.0f : __expf(l[p] - mx); den += l[p]; }
+        den = grp8_sum(den);
+        const float inv = (den > 0.0f) ? 1.0f / den : 0.0f;
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) {
+          const float av = l[p] * inv;
+          acc[p][h] = av;
+          if (slot[p] >= 0) {
+            if (a.attn != nullptr) at[(i * S + slot[p]) * H + h] = av;
+            if (av != 0.0f) {   // masked slots may carry 5e5 / NaN edge features: skip, never multiply
+              const float4 e = R.efv[p];
+              z0 = fmaf(av, e.x, z0); z1 = fmaf(av, e.y, z1); z2 = fmaf(av, e.z, z2); z3 = fmaf(av, e.w, z3);
+            }
+          }
+        }
+        z0 = grp8_sum(z0); z1 = grp8_sum(z1); z2 = grp8_sum(z2); z3 = grp8_sum(z3);
+        if (live && sub == 0) *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + F) = make_float4(z0, z1, z2, z3);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NPR; ++p) acc[p][h] = 0.0f;
+      }
+#pragma unroll
+      for (int p = 0; p < NPR; ++p) PT[(il * 4 + h) * PL + p * 8 + sub] = acc[p][h];
+    }
+    {
+      float pa[PC];
+#pragma unroll
+      for (int k = 0; k < PC / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(PT + (il * 4 + hA) * PL + k * 4);
+        pa[k * 4] = v.x; pa[k * 4 + 1] = v.y; pa[k * 4 + 2] = v.z; pa[k * 4 + 3] = v.w;
+      }
+      f32x4g az[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) az[q] = f32x4g{0.f, 0.f, 0.f, 0.f};
+      const int fq = (g2 * 4 + c) * 4;
+#pragma unroll
+      for (int kk = 0; kk < NSP; ++kk) {
+        const float4 b = *reinterpret_cast<const float4*>(XS + kk * ABD_XL + fq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) az[q] = mfma4(pa[kk], f4e(b)[q], az[q]);
+      }
+      if constexpr (HITS) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float4 b = *reinterpret_cast<const float4*>(XH + (il * 8 + m) * ABD_XL + il * 8 + fq);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) az[q] = mfma4(pa[NSP + m], f4e(b)[q], az[q]);
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (h < H) *reinterpret_cast<float4*>(zc + i * Kp + F + h * Wd + fq) = make_float4(az[0][h], az[1][h], az[2][h], az[3][h]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PS; ++p) {
+      const int row = p * 8 + il;
+      if (row < n) *reinterpret_cast<float4*>(zc + row * Kp + sub * 4) = *reinterpret_cast<const float4*>(XS + row * ABD_XL + sub * 4);
+    }
+    {
+      const int wpad = Kp - kc;                                  // >= 1: the constant column, then zeros
+      for (int ii = lane; ii < n; ii += 64)
+        for (int cc = 0; cc < wpad; ++cc) zc[ii * Kp + kc + cc] = (cc == 0) ? 1.0f : 0.0f;
+    }
+  };
+  Regs cur;
+  load(g, cur);
+  for (;;) {
+    stage(cur);
+    const int gn = g + stride;
+    const bool more = gn < a.G;                                // wave-uniform
+    Regs nxt;
+    if (more) load(gn, nxt);
+    compute(g, cur);
+    if (!more) break;
+    cur = nxt;
+    g = gn;
   }
 }
 
@@ -2118,8 +2342,35 @@ static bool attn_bd_shape(const Topo& t, int F, int H, int& PS, bool& hits) {
 template <int PS, bool HITS, int AB, bool XOF>
 static void launch_attn_bd_x(const AttnArgs& a, hipStream_t s, bool bwd) {
   using L = AbdLds<PS, HITS>;
-  if (bwd) hipLaunchKernelGGL((attn_bwd_bd_kernel<PS, HITS, AB, XOF>), dim3(a.G), dim3(64), sizeof(float) * L::BWD, s, a);
-  else hipLaunchKernelGGL((attn_fwd_bd_kernel<PS, HITS, AB, XOF>), dim3((a.G + 1) / 2), dim3(128), sizeof(float) * 2 * L::FWD, s, a);
+  if (bwd) { hipLaunchKernelGGL((attn_bwd_bd_kernel<PS, HITS, AB, XOF>), dim3(a.G), dim3(64), sizeof(float) * L::BWD, s, a); return; }
+  if constexpr (AB == 1) {
+    if (!getenv("DGPPO_ATTN_NO_PERSIST")) {
+      // persistent waves with the next graph's loads in flight: as many 2-wave workgroups as fit the chip (LDS-limited), unless
+      // the launch is small enough that every graph gets its own wave anyway
+      static thread_local int cap = 0;
+      if (cap == 0) {
+        int per_cu = 0, dev = 0, cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&attn_fwd_bdp_kernel<PS, HITS, XOF>), 128,
+                                                         sizeof(float) * 2 * L::FWD) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus < 1) cus = 256;
+        cap = per_cu * cus;
+      }
+      const int wgs = (a.G + 1) / 2;
+      if (const char* force = getenv("DGPPO_ATTN_PERSIST_WGS")) {     // tests: walk several graphs per wave on a tiny launch
+        const int fw = atoi(force);
+        if (fw > 0) {
+          hipLaunchKernelGGL((attn_fwd_bdp_kernel<PS, HITS, XOF>), dim3(fw < wgs ? fw : wgs), dim3(128), sizeof(float) * 2 * L::FWD, s, a);
+          return;
+        }
+      }
+      if (wgs > 2 * cap) {        // (smaller launches: one graph per wave in the leaner kernel below — more waves per CU)
+        hipLaunchKernelGGL((attn_fwd_bdp_kernel<PS, HITS, XOF>), dim3(cap), dim3(128), sizeof(float) * 2 * L::FWD, s, a);
+        return;
+      }
+    }
+  }
+  hipLaunchKernelGGL((attn_fwd_bd_kernel<PS, HITS, AB, XOF>), dim3((a.G + 1) / 2), dim3(128), sizeof(float) * 2 * L::FWD, s, a);
 }
 template <int PS, bool HITS, int AB>
 static void launch_attn_bd_one(const AttnArgs& a, hipStream_t s, bool bwd) {

@@ -599,7 +599,8 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
 
     families = {"default": {}, "block": {"DGPPO_ATTN_BLOCK": "1"}, "valu": {"DGPPO_ATTN_VALU": "1"},
                 "dense8": {"DGPPO_ATTN_DENSE8": "1"},      # F = 8: the matrix-core wave kernels instead of the slot-sparse ones
-                "wave": {"DGPPO_ATTN_NO_BD": "1"}}         # F = 32: the dense one-wave-per-graph tiles instead of the block-diagonal form
+                "wave": {"DGPPO_ATTN_NO_BD": "1"},         # F = 32: the dense one-wave-per-graph tiles instead of the block-diagonal form
+                "persist": {"DGPPO_ATTN_PERSIST_WGS": "3"}}  # F = 32 forward: persistent waves, 6 graphs each, next graph's loads in flight
     outs = {}
     for name, env in families.items():
         for k, v in env.items():
@@ -611,7 +612,7 @@ def test_attention_kernel_families_agree(cuda, monkeypatch, F, Kp):
     for k, v in ref.items():
         assert torch.isfinite(v).all(), f"default path left non-finite values in {k}"
     _close(ref["dq_only"], ref["dq"], 2e-5, "dqt-only backward vs full backward")
-    for name in ("block", "valu", "dense8", "wave"):
+    for name in ("block", "valu", "dense8", "wave", "persist"):
         for k in ref:
             _close(outs[name][k], ref[k], 2e-5, f"{name}.{k}")
 
@@ -664,7 +665,7 @@ def test_attention_wave_kernels_across_topologies(cuda, monkeypatch, kind, n, n_
 
 
 @pytest.mark.parametrize("kind,n,n_obs", [(0, 8, 3), (0, 3, 0), (0, 10, 3), (1, 6, 2), (3, 4, 3), (2, 16, 8)])
-def test_attention_with_recomputed_other_nodes(cuda, kind, n, n_obs):
+def test_attention_with_recomputed_other_nodes(cuda, monkeypatch, kind, n, n_obs):
     """dgppo_attn_fwd_xo / _bwd_xo recompute the sender rows of the nodes without incoming edges, relu(Xo_raw Wo + bo), inside
     the kernel (gnn.py:109-111 with aggr = 0 feeding gnn.py:85-117); they must agree with materialising those rows (torch) and
     calling dgppo_attn_fwd / _bwd, forward and backward, with and without the ReLU mask on dXo."""
@@ -708,6 +709,12 @@ def test_attention_with_recomputed_other_nodes(cuda, kind, n, n_obs):
         torch.cuda.synchronize()
         return dict(z=z, at=at, dq=dq, dXa=dXa, dXo=dXo)
 
+    monkeypatch.setenv("DGPPO_ATTN_PERSIST_WGS", "2")            # the persistent forward (4-5 graphs per wave) on the same inputs
+    pers = run(True, False)
+    monkeypatch.delenv("DGPPO_ATTN_PERSIST_WGS")
+    plain = run(True, False)
+    for k in plain:
+        assert torch.equal(pers[k], plain[k]), f"persistent forward differs in {k}"
     for relu_xo in (False, True):
         got, ref = run(True, relu_xo), run(False, relu_xo)
         for k in ref:
