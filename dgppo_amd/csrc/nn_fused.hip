@@ -854,6 +854,155 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))
   }
 }
 
+// ---- the same step with rows per WAVE and the weights in LDS (inference form: nothing saved for a backward) -----------------
+// As mlp_gi_fwd_rw_kernel: a wave carries 16 rows through the GRU step and the head; Wh (48 KB), W1 and W2 sit in LDS once per CU,
+// shared by the 16 waves of the one workgroup; h' and u change from the C/D layout to the A layout through a wave-private LDS
+// tile; no barrier after the staging.  The rollout step (32 768 rows) took 19 us with the tiled kernel above (two workgroup
+// barriers per 32-row tile, 212 VGPRs: two workgroups per CU) for 9 us of matrix-core work.
+#define RWH_W1L 65
+template <bool TWO>
+__global__ void __launch_bounds__(64 * RW_WAVES) gru1_head_fwd_rw_kernel(GruHeadArgs a) {
+  extern __shared__ float sm[];
+  float* sWh = sm;                                // [64][193]
+  float* sW1 = sWh + 64 * RW_WIL;                 // TWO: [64][65] (64 columns); else [64][17] in the same stride-65 rows (16 columns)
+  float* sW2 = sW1 + 64 * RWH_W1L;                // TWO: [64][17]
+  float* sB = sW2 + 64 * 17;                      // bhn (64), b1 (64), b2 (16)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lq = lane >> 4;
+  float* sY = sB + 144 + w * (16 * RW_YL);
+  {
+    static_assert(RW_WAVES == 16, "the staging below assumes 1024 threads");
+    float4 vh[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) vh[j] = reinterpret_cast<const float4*>(a.Wh)[j * 1024 + tid];
+    float w1v[4] = {0.f, 0.f, 0.f, 0.f};
+    float w2v = 0.0f;
+    if (TWO) {
+      const float4 v = reinterpret_cast<const float4*>(a.W1)[tid];          // [64][64]
+      w1v[0] = v.x; w1v[1] = v.y; w1v[2] = v.z; w1v[3] = v.w;
+      { const int k = tid >> 4, c = tid & 15; w2v = (c < a.n_out) ? a.W2[k * a.n_out + c] : 0.0f; }
+    } else {
+      const int k = tid >> 4, c = tid & 15;
+      w1v[0] = (c < a.n_out) ? a.W1[k * a.n_out + c] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = j * 1024 + tid, k = q / 48, c = (q - k * 48) * 4;
+      float* d = sWh + k * RW_WIL + c;
+      d[0] = vh[j].x; d[1] = vh[j].y; d[2] = vh[j].z; d[3] = vh[j].w;
+    }
+    if (TWO) {
+      const int k = tid >> 4, c = (tid & 15) * 4;
+      float* d = sW1 + k * RWH_W1L + c;
+      d[0] = w1v[0]; d[1] = w1v[1]; d[2] = w1v[2]; d[3] = w1v[3];
+      sW2[(tid >> 4) * 17 + (tid & 15)] = w2v;
+    } else {
+      sW1[(tid >> 4) * RWH_W1L + (tid & 15)] = w1v[0];
+    }
+    if (tid < 64) { sB[tid] = a.bhn[tid]; sB[64 + tid] = TWO ? a.b1[tid] : ((tid < a.n_out) ? a.b1[tid] : 0.0f); }
+    if (tid < 16) sB[128 + tid] = (TWO && tid < a.n_out) ? a.b2[tid] : 0.0f;
+  }
+  __syncthreads();
+  const int n_tiles = (a.M + 15) >> 4;
+  for (int tile = w * gridDim.x + blockIdx.x; tile < n_tiles; tile += gridDim.x * RW_WAVES) {
+    const int row0 = tile * 16;
+    // A operand: h0 row li, columns lq * 16 .. + 15 (zeros without h0); the same rows again in the C/D layout for the update
+    float A[16];
+    {
+      int row = row0 + li;
+      row = row < a.M ? row : a.M - 1;
+      if (a.h0 != nullptr) {
+        const float4* p = reinterpret_cast<const float4*>(a.h0 + (size_t)row * FZ_H + lq * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 v = p[j]; A[4 * j] = v.x; A[4 * j + 1] = v.y; A[4 * j + 2] = v.z; A[4 * j + 3] = v.w; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) A[j] = 0.0f;
+      }
+    }
+    float hp[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + lq * 4 + r;
+        row = row < a.M ? row : a.M - 1;
+        hp[ct][r] = (a.h0 != nullptr) ? a.h0[(size_t)row * FZ_H + ct * 16 + li] : 0.0f;
+      }
+    // hidden column group ct (16 columns): r, z, n gate tiles ct, ct + 4, ct + 8 of gh = h0 Wh, seeded with the input projection gi
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      f32x4 ar, az, an = f32x4{0.f, 0.f, 0.f, 0.f};
+      float gn[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + lq * 4 + r;
+        row = row < a.M ? row : a.M - 1;
+        const float* gp = a.gi + (size_t)row * 192 + ct * 16 + li;
+        ar[r] = gp[0]; az[r] = gp[64]; gn[r] = gp[128];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float* wr = sWh + (lq * 16 + kk) * RW_WIL + ct * 16 + li;
+        ar = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wr[0], ar, 0, 0, 0);
+        az = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wr[64], az, 0, 0, 0);
+        an = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wr[128], an, 0, 0, 0);
+      }
+      const float bn = sB[ct * 16 + li];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float rg = gate_sigmoid(ar[r]);
+        const float zg = gate_sigmoid(az[r]);
+        const float ng = gate_tanh(gn[r] + rg * (an[r] + bn));
+        const float hnew = (1.0f - zg) * ng + zg * hp[ct][r];
+        sY[(lq * 4 + r) * RW_YL + ct * 16 + li] = hnew;
+        const int row = row0 + lq * 4 + r;
+        if (row < a.M) a.hs[(size_t)row * FZ_H + ct * 16 + li] = hnew;
+      }
+    }
+    // h' as the next A operand
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(sY + li * RW_YL + lq * 16 + 4 * j);
+      A[4 * j] = v.x; A[4 * j + 1] = v.y; A[4 * j + 2] = v.z; A[4 * j + 3] = v.w;
+    }
+    if (TWO) {
+      f32x4 au[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) au[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float* wr = sW1 + (lq * 16 + kk) * RWH_W1L + li;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) au[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], wr[ct * 16], au[ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float b = sB[64 + ct * 16 + li];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sY[(lq * 4 + r) * RW_YL + ct * 16 + li] = au[ct][r] + b;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(sY + li * RW_YL + lq * 16 + 4 * j);
+        A[4 * j] = v.x; A[4 * j + 1] = v.y; A[4 * j + 2] = v.z; A[4 * j + 3] = v.w;
+      }
+    }
+    {
+      f32x4 ao = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* sWo = TWO ? sW2 : sW1;
+      const int ld = TWO ? 17 : RWH_W1L;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) ao = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], sWo[(lq * 16 + kk) * ld + li], ao, 0, 0, 0);
+      const float b = TWO ? sB[128 + li] : sB[64 + li];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + lq * 4 + r;
+        if (row < a.M && li < a.n_out) a.out[(size_t)row * a.n_out + li] = ao[r] + b;
+      }
+    }
+  }
+}
+
 extern "C" int32_t dgppo_gru1_head_fwd(const float* gi, const float* Wh, const float* bhn, const float* h0, const float* W1,
                                        const float* b1, const float* W2, const float* b2, float* hs, float* hprev,
                                        float* gates, float* u, float* out, int32_t M, int32_t n_out, void* stream) {
@@ -864,6 +1013,30 @@ extern "C" int32_t dgppo_gru1_head_fwd(const float* gi, const float* Wh, const f
   DGPPO_REQUIRE(two || !u, "gru1_head_fwd: u is only produced by the two-layer head");
   if (M == 0) return 0;
   GruHeadArgs a{gi, Wh, bhn, h0, W1, b1, W2, b2, hs, hprev, gates, u, out, M, n_out};
+  // inference (nothing saved): rows per wave, weights in LDS
+  if (!hprev && !gates && !u && ((reinterpret_cast<uintptr_t>(Wh) | reinterpret_cast<uintptr_t>(W1) | reinterpret_cast<uintptr_t>(h0)) & 15) == 0 &&
+      !getenv("DGPPO_GRU1_TILED")) {
+    static thread_local int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    }
+    const size_t smem_rw = sizeof(float) * (64 * RW_WIL + 64 * RWH_W1L + 64 * 17 + 144 + RW_WAVES * 16 * RW_YL);
+    static thread_local bool attr[2] = {false, false};
+    if (!attr[two]) {
+      const void* f = two ? reinterpret_cast<const void*>(&gru1_head_fwd_rw_kernel<true>)
+                          : reinterpret_cast<const void*>(&gru1_head_fwd_rw_kernel<false>);
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_rw);
+      DGPPO_REQUIRE(e == hipSuccess, "gru1_head_fwd: cannot reserve %zu bytes of LDS per workgroup: %s", smem_rw, hipGetErrorString(e));
+      attr[two] = true;
+    }
+    const int tiles16 = (M + 15) / 16, grid_rw = tiles16 < cus ? tiles16 : cus;
+    if (two) hipLaunchKernelGGL(gru1_head_fwd_rw_kernel<true>, dim3(grid_rw), dim3(64 * RW_WAVES), smem_rw, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gru1_head_fwd_rw_kernel<false>, dim3(grid_rw), dim3(64 * RW_WAVES), smem_rw, (hipStream_t)stream, a);
+    DGPPO_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = sizeof(float) * 3 * FZ_RB * FZ_HL;
   const void* fn = two ? reinterpret_cast<const void*>(&gru1_head_fwd_kernel<true>)
                        : reinterpret_cast<const void*>(&gru1_head_fwd_kernel<false>);
